@@ -1,0 +1,44 @@
+"""Deterministic synthetic NeRF weights in the reference's ``NeRFModel`` state-dict layout.
+
+The trained checkpoints of the reference are not in its tree (.MISSING_LARGE_BLOBS:1-4), so the
+benchmark and the parity tests use weights from a counter-based numpy generator: the same seed
+gives the same tensors on every machine, so nothing large has to be committed.
+
+Layout follows nerf/models/nerf_model.py:32-43 (``nn.Linear`` weights are ``[out, in]``, fp32):
+``_pts_linears.{i}``, ``_views_linears.0``, ``_feature_linear``, ``_alpha_linear``, ``_rgb_linear``.
+"""
+from __future__ import annotations
+
+from typing import Dict, Tuple
+
+import numpy as np
+
+
+def layer_shapes(D: int, W: int, in_xyz: int = 63, in_dir: int = 27,
+                 skips: Tuple[int, ...] = (4,)) -> Dict[str, Tuple[int, int]]:
+    """name -> (out, in) for every Linear of NeRFModel(D, W, use_view_dirs=True)."""
+    shapes = {"_pts_linears.0": (W, in_xyz)}
+    for i in range(D - 1):
+        # nerf_model.py:33-35: layer i+1 takes the skip input when i is in `skips`
+        shapes[f"_pts_linears.{i + 1}"] = (W, W + in_xyz if i in skips else W)
+    shapes["_views_linears.0"] = (W // 2, in_dir + W)
+    shapes["_feature_linear"] = (W, W)
+    shapes["_alpha_linear"] = (1, W)
+    shapes["_rgb_linear"] = (3, W // 2)
+    return shapes
+
+
+def make_state_dict(seed: int, D: int = 8, W: int = 256, in_xyz: int = 63, in_dir: int = 27,
+                    skips: Tuple[int, ...] = (4,), w_gain: float = 2.0, b_gain: float = 1.0) -> Dict[str, np.ndarray]:
+    """U(-w_gain/sqrt(fan_in), +w_gain/sqrt(fan_in)) weights, U(+-b_gain/sqrt(fan_in)) biases.
+
+    The gain is about twice PyTorch's default init so that per-sample opacity spans 0..1 and the
+    rendered image is not flat; one Philox stream per tensor keyed by (seed, index).
+    """
+    out: Dict[str, np.ndarray] = {}
+    for idx, (name, (n_out, n_in)) in enumerate(layer_shapes(D, W, in_xyz, in_dir, skips).items()):
+        rng = np.random.Generator(np.random.Philox(key=[seed, idx]))
+        kw, kb = w_gain / np.sqrt(n_in), b_gain / np.sqrt(n_in)
+        out[f"{name}.weight"] = rng.uniform(-kw, kw, size=(n_out, n_in)).astype(np.float32)
+        out[f"{name}.bias"] = rng.uniform(-kb, kb, size=(n_out,)).astype(np.float32)
+    return out
