@@ -1,0 +1,136 @@
+/*
+ * nwe.h -- C ABI of the MI355X-native NeRF volume-rendering path (libnwe_hip.so).
+ *
+ * The reference (dmjovan/NeRF-Workspaces-Explorer) has no FFI layer: its hot path is plain PyTorch
+ * behind the public surface of NeRFReplicaInferenceHandler.  Each entry point below names the
+ * reference interface it replaces (paths relative to the reference root).  Plain pointers and sizes
+ * only; no torch types.  All functions return 0 on success, a NWE_ERR_* code otherwise, never throw,
+ * and leave a message retrievable with nwe_last_error().  A context is not thread-safe.
+ */
+#ifndef NWE_H
+#define NWE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct nwe_ctx nwe_ctx;
+
+enum {
+    NWE_OK = 0,
+    NWE_ERR_INVALID = 1,     /* bad argument (null pointer, size, shape) */
+    NWE_ERR_UNSUPPORTED = 2, /* network shape / precision combination has no kernel */
+    NWE_ERR_HIP = 3,         /* a HIP runtime call failed; message holds hipGetErrorString */
+    NWE_ERR_STATE = 4        /* call order: network / sampling tables not set */
+};
+
+enum { NWE_NET_COARSE = 0, NWE_NET_FINE = 1 };
+
+/* Arithmetic of the MLP GEMMs.  Everything else (rays, sampling, encoding, compositing) is fp32
+ * (with the fp64 running products/sums torch's CPU cumprod/cumsum use) in every mode. */
+enum {
+    NWE_PREC_F16X3 = 0, /* MFMA f16, operands split hi+lo, 3 products, fp32 accumulate: fp32-grade (default) */
+    NWE_PREC_F16X1 = 1, /* MFMA f16 single product: ~1e-3 abs on RGB, PSNR > 50 dB */
+    NWE_PREC_F32 = 2    /* fp32 FMA chain on the vector ALU, any layer shape: on-device reference */
+};
+
+/* bits OR-ed into *nwe_outputs.flags: the reference only prints
+ * "[Numerical Error] <key> contains NaN or inf." (nerf_replica_inference_handler.py:273-275) */
+enum {
+    NWE_FLAG_RGB = 1u << 0, NWE_FLAG_DEPTH = 1u << 1, NWE_FLAG_ACC = 1u << 2, NWE_FLAG_DISP = 1u << 3,
+    NWE_FLAG_RGB_COARSE = 1u << 4, NWE_FLAG_DEPTH_COARSE = 1u << 5, NWE_FLAG_ACC_COARSE = 1u << 6,
+    NWE_FLAG_DISP_COARSE = 1u << 7, NWE_FLAG_RAW = 1u << 8, NWE_FLAG_ZSTD = 1u << 9
+};
+
+/* Device output buffers, owned by the caller; any pointer may be NULL (that output is skipped).
+ * R = number of rays of the call, S = n_samples + n_importance.  Keys mirror the output dict of
+ * NeRFReplicaInferenceHandler._volumetric_rendering (nerf_replica_inference_handler.py:256-268).
+ * When n_importance == 0 the "fine" slots receive the coarse results (the reference raises
+ * UnboundLocalError there, :263). */
+typedef struct nwe_outputs {
+    float *rgb;          /* [R,3]   rgb_fine    */
+    float *depth;        /* [R]     depth_fine  */
+    float *acc;          /* [R]     acc_fine    */
+    float *disp;         /* [R]     disp_fine   */
+    float *z_std;        /* [R]     z_std       */
+    float *rgb_coarse;   /* [R,3]               */
+    float *depth_coarse; /* [R]                 */
+    float *acc_coarse;   /* [R]                 */
+    float *disp_coarse;  /* [R]                 */
+    float *raw_coarse;   /* [R,n_samples,4]  network output, [rgb_raw(3), sigma_raw] */
+    float *raw_fine;     /* [R,S,4]             */
+    float *z_fine;       /* [R,S]  sorted sample depths of the fine pass (handler.py:243) */
+    uint32_t *flags;     /* [1]    NWE_FLAG_* bits, OR-ed (caller zeroes it) */
+} nwe_outputs;
+
+/* Create a context bound to HIP device `device`.  device == -1 creates a host-only context that can
+ * pack networks (for CPU tests of the packer) but cannot render.
+ * Replaces: NeRFReplicaInferenceHandler.__init__ device side (handler.py:25-86). */
+int nwe_create(nwe_ctx **out, int device);
+void nwe_destroy(nwe_ctx *ctx);
+
+/* Message of the last failed call on `ctx` (or of the last failed nwe_create when ctx == NULL). */
+const char *nwe_last_error(const nwe_ctx *ctx);
+
+/* Upload one NeRFModel (nerf/models/nerf_model.py:10-43, use_view_dirs=True) from HOST fp32 tensors in
+ * PyTorch nn.Linear layout ([out,in] row-major, y = x W^T + b).  Copied and repacked inside; the caller
+ * may free its buffers on return.  Replaces load_state_dict + .cuda() (handler.py:106-141).
+ *   depth, width   D, W of the density trunk
+ *   in_xyz,in_dir  encoded input widths (63, 27): 3 + 6*num_freqs
+ *   skip_layer     i such that gamma(x) is concatenated in front of h AFTER layer i's ReLU
+ *                  (nerf_model.py:58-59; 4 for D=8), or -1
+ *   w, b           depth+4 pointers each, ordered: _pts_linears[0..depth-1], _views_linears[0],
+ *                  _feature_linear, _alpha_linear, _rgb_linear */
+int nwe_set_network(nwe_ctx *ctx, int which, int depth, int width, int in_xyz, int in_dir, int skip_layer,
+                    const float *const *w, const float *const *b);
+
+/* Sampling tables computed by the host with torch.linspace (its bits are not i/(n-1)):
+ *   t_vals[n_samples] = linspace(0,1,Ns) and one_minus_t[n_samples] = 1 - t_vals  (handler.py:216-218)
+ *   u[n_importance]   = linspace(0,1,Ni)                                        (nerf/rays/rays.py:95)
+ * n_importance may be 0 (coarse only; u may then be NULL). */
+int nwe_set_sampling(nwe_ctx *ctx, const float *t_vals, const float *one_minus_t, int n_samples,
+                     const float *u, int n_importance);
+
+/* Render rays [row_begin,row_end) x [0,W) of n_poses pinhole views.  c2w: HOST, n_poses*16 floats,
+ * row-major 4x4 camera-to-world.  Output ray index = (p*(row_end-row_begin) + (h-row_begin))*W + w.
+ * Ray generation follows nerf/rays/rays.py:6-71; the render loop nerf_replica_inference_handler.py:203-277.
+ * Asynchronous on `stream` (a hipStream_t, NULL = default stream).
+ * Replaces: create_rays + rays.cuda() + _render_rays of render_coordinates (handler.py:172-177). */
+int nwe_render(nwe_ctx *ctx, const float *c2w, int n_poses, int H, int W, float fx, float fy, float cx, float cy,
+               float near, float far, int row_begin, int row_end, int precision, const nwe_outputs *out,
+               void *stream);
+
+/* Render precomputed rays: DEVICE [n_rays,11] fp32 = [o(3) d(3) near far viewdir(3)] (rays.py:26-30).
+ * Replaces: NeRFReplicaInferenceHandler._render_rays(flat_rays) (handler.py:187-201). */
+int nwe_render_rays(nwe_ctx *ctx, const float *rays_dev, int64_t n_rays, int precision, const nwe_outputs *out,
+                    void *stream);
+
+/* uint8 = (255 * clip(x,0,1)) truncated, elementwise over n floats on the device.
+ * Replaces: to8b_np (nerf/models/model_utils.py:9) of render_coordinates' tail (handler.py:183). */
+int nwe_to8b(nwe_ctx *ctx, const float *rgb_dev, uint8_t *out_dev, int64_t n, void *stream);
+
+/* Algorithmic FLOPs (2 x GEMM MACs of the reference formulation) of one MLP evaluation of network `which`. */
+int64_t nwe_flops_per_eval(const nwe_ctx *ctx, int which);
+
+/* Time of the most recent render launch on this context, from HIP events recorded on its stream
+ * around the kernel; blocks until that launch has finished.  Returns < 0 if nothing was launched. */
+float nwe_last_kernel_ms(nwe_ctx *ctx);
+
+/* --- test hooks ------------------------------------------------------------------------------- */
+
+/* Size in bytes / host copy of the MFMA weight stream packed for network `which` (0 if that network
+ * has no MFMA kernel).  Layout: see DESIGN.md "weight stream".  Works on host-only contexts. */
+int64_t nwe_packed_bytes(const nwe_ctx *ctx, int which);
+int nwe_packed_copy(const nwe_ctx *ctx, int which, void *host_dst, int64_t bytes);
+
+/* Device self-test of the hardware assumptions the MFMA kernel relies on (fragment layouts of
+ * v_mfma_f32_32x32x16_f16, fp16 subnormal operands, LDS-DMA lane order).  report[0..7] receives
+ * mismatch counts / measured values; returns NWE_OK when every assumption holds. */
+int nwe_selftest(nwe_ctx *ctx, int32_t *report8);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NWE_H */

@@ -1,0 +1,16 @@
+"""MI355X-native NeRF volume-rendering path behind the call surface of
+dmjovan/NeRF-Workspaces-Explorer's ``NeRFReplicaInferenceHandler``.
+
+Imported as ``nwe_amd`` through the shim at the repository root (the directory name is not a valid
+identifier).  ``synthetic``/``config``/``camera_poses`` are pure host helpers; anything that renders goes
+through ``libnwe_hip.so`` and raises if it has not been built.
+"""
+from . import synthetic                                    # noqa: F401
+from .camera_poses import get_camera_poses_from_list_of_coordinates   # noqa: F401
+from .config import Config, ConfigError                    # noqa: F401
+from .data_descriptors import COORD, HW, XYZ               # noqa: F401
+from .handler import NeRFReplicaInferenceHandler, load_checkpoint, pinhole_intrinsics   # noqa: F401
+from .renderer import Renderer                             # noqa: F401
+
+__all__ = ["NeRFReplicaInferenceHandler", "Renderer", "COORD", "HW", "XYZ", "Config", "ConfigError",
+           "get_camera_poses_from_list_of_coordinates", "load_checkpoint", "pinhole_intrinsics", "synthetic"]

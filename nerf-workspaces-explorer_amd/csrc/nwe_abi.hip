@@ -1,0 +1,387 @@
+// C ABI of libnwe_hip.so (include/nwe.h): context, weight packing, table upload, kernel launches.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "nwe_host.h"
+
+using namespace nwe;
+
+namespace {
+
+struct NetState {
+    bool set = false;
+    int D = 0, W = 0, in_xyz = 0, in_dir = 0, skip = -1;
+    int64_t flops = 0;
+    std::vector<float> blob;       // fp32 kernel: per layer Wt[k][n] then bias
+    NetF32 f32 = {};
+    float* d_blob = nullptr;
+    bool mfma_ok = false;
+    std::vector<uint8_t> stream;   // MFMA kernel: 1-KiB tiles in consumption order
+    NetMfma mf = {};
+    uint8_t* d_stream = nullptr;
+};
+
+thread_local std::string g_create_error;
+
+}  // namespace
+
+struct nwe_ctx {
+    int device = -1;
+    bool host_only = false;
+    NetState net[2];
+    float *d_t = nullptr, *d_omt = nullptr, *d_u = nullptr;
+    int ns = 0, ni = 0;
+    float* d_poses = nullptr;
+    int poses_cap = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timed = false;
+    std::string err;
+};
+
+namespace {
+
+int fail(nwe_ctx* c, int code, const std::string& msg) {
+    if (c) c->err = msg; else g_create_error = msg;
+    return code;
+}
+
+#define HIPCHK(ctx, expr)                                                                          \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return fail(ctx, NWE_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));      \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// packing for the MFMA kernel.  Must mirror nwe_kernel_mfma.hip (encode(), split_tile(), tile_mma()).
+// ---------------------------------------------------------------------------------------------
+
+// Column of gamma(v) (embedding.py:24-48 order: identity(3), then per band sin(3), cos(3)) that lane half h
+// holds in element j of k-step s.  nb = bands per lane half (5 for xyz, 2 for dirs).  -1 = padding.
+int gamma_col(int nb, int s, int h, int j) {
+    const int q = s * 8 + j;
+    if (q < 6 * nb) {
+        const int pair = q >> 1, bl = pair / 3, c = pair % 3, band = bl + nb * h;
+        return 3 + 6 * band + ((q & 1) ? 3 : 0) + c;
+    }
+    if (q == 6 * nb) return h ? 2 : 0;
+    if (q == 6 * nb + 1) return h ? -1 : 1;
+    return -1;
+}
+
+// Feature index that element j of k-step s holds in lane half h when a 32x32 accumulator tile is reused
+// as the next B operand: tile rt = s/2, register r = 8*(s&1) + j, row = (r&3) + 8*(r>>2) + 4*h.
+int hidden_col(int s, int h, int j) { return 16 * s + 8 * (j >> 2) + 4 * h + (j & 3); }
+
+struct Segment {
+    int kind;     // 0 = hidden, 1 = gamma(x), 2 = gamma(d)
+    int ksteps;
+    int col_off;  // column offset of this segment in the layer's [out,in] weight
+};
+
+struct RowMap {   // which weight row feeds tile row i (or -1)
+    int n_out;
+    int dup4;     // 1: rows 4..7 repeat rows 0..3 (head tiles read by both lane halves)
+    int operator()(int rt, int i) const {
+        int r = rt * 32 + i;
+        if (dup4) { if (i >= 8) return -1; r = i & 3; }
+        return r < n_out ? r : -1;
+    }
+};
+
+void put_tile_pair(std::vector<uint8_t>& out, const float* w, int ld, const RowMap& rows, int rt, const Segment& sg, int s) {
+    const size_t base = out.size();
+    out.resize(base + 2 * kTileBytes, 0);
+    _Float16* hi = reinterpret_cast<_Float16*>(out.data() + base);
+    _Float16* lo = reinterpret_cast<_Float16*>(out.data() + base + kTileBytes);
+    for (int lane = 0; lane < 64; ++lane) {
+        const int i = lane & 31, h = lane >> 5;
+        const int row = rows(rt, i);
+        for (int j = 0; j < 8; ++j) {
+            int col = sg.kind == 0 ? hidden_col(s, h, j) : gamma_col(sg.kind == 1 ? 5 : 2, s, h, j);
+            float v = 0.f;
+            if (row >= 0 && col >= 0) v = w[(size_t)row * ld + sg.col_off + col];
+            const _Float16 vh = (_Float16)v;
+            hi[lane * 8 + j] = vh;
+            lo[lane * 8 + j] = (_Float16)((v - (float)vh) * (float)(1 << kLoShift));
+        }
+    }
+}
+
+void put_chunk(std::vector<uint8_t>& out, const float* w, const float* b, int ld, const RowMap& rows, int rt,
+               const std::vector<Segment>& segs) {
+    const size_t base = out.size();
+    out.resize(base + kTileBytes, 0);
+    float* bias = reinterpret_cast<float*>(out.data() + base);
+    for (int i = 0; i < 32; ++i) { const int r = rows(rt, i); bias[i] = r >= 0 ? b[r] : 0.f; }
+    for (const Segment& sg : segs)
+        for (int s = 0; s < sg.ksteps; ++s) put_tile_pair(out, w, ld, rows, rt, sg, s);
+}
+
+// Stream order = the order mlp_eval() consumes chunks in.
+void pack_mfma(NetState& n, const float* const* w, const float* const* b) {
+    const int D = n.D, W = n.W, KH = W / 16;
+    n.stream.clear();
+    auto layer = [&](int li, int n_out, int ld, int n_tiles, int dup4, const std::vector<Segment>& segs) {
+        RowMap rows{n_out, dup4};
+        for (int rt = 0; rt < n_tiles; ++rt) put_chunk(n.stream, w[li], b[li], ld, rows, rt, segs);
+    };
+    layer(0, W, n.in_xyz, W / 32, 0, {{1, 4, 0}});
+    for (int i = 1; i < D; ++i) {
+        if (i == n.skip + 1) layer(i, W, W + n.in_xyz, W / 32, 0, {{1, 4, 0}, {0, KH, n.in_xyz}});   // cat([pts, h]), nerf_model.py:59
+        else layer(i, W, W, W / 32, 0, {{0, KH, 0}});
+    }
+    const int iv = D, ife = D + 1, ia = D + 2, irgb = D + 3;
+    layer(ife, W, W, W / 32, 0, {{0, KH, 0}});
+    layer(ia, 1, W, 1, 1, {{0, KH, 0}});
+    layer(iv, W / 2, W + n.in_dir, W / 64, 0, {{0, KH, 0}, {2, 2, W}});                               // cat([feature, views]), :66
+    layer(irgb, 3, W / 2, 1, 1, {{0, KH / 2, 0}});
+}
+
+void pack_f32(NetState& n, const float* const* w, const float* const* b) {
+    n.blob.clear();
+    auto add = [&](int li, int K, int N) {
+        LayerF32 L; L.K = K; L.N = N; L.wt_off = (int64_t)n.blob.size();
+        n.blob.resize(n.blob.size() + (size_t)K * N);
+        float* wt = n.blob.data() + L.wt_off;
+        for (int k = 0; k < K; ++k) for (int o = 0; o < N; ++o) wt[(size_t)k * N + o] = w[li][(size_t)o * K + k];
+        L.b_off = (int64_t)n.blob.size();
+        n.blob.insert(n.blob.end(), b[li], b[li] + N);
+        while (n.blob.size() % 4) n.blob.push_back(0.f);
+        return L;
+    };
+    const int D = n.D, W = n.W;
+    n.f32 = {};
+    n.f32.D = D; n.f32.W = W; n.f32.in_xyz = n.in_xyz; n.f32.in_dir = n.in_dir; n.f32.skip = n.skip;
+    n.f32.pts[0] = add(0, n.in_xyz, W);
+    for (int i = 1; i < D; ++i) n.f32.pts[i] = add(i, i == n.skip + 1 ? W + n.in_xyz : W, W);
+    n.f32.views = add(D, W + n.in_dir, W / 2);
+    n.f32.feature = add(D + 1, W, W);
+    n.f32.alpha = add(D + 2, W, 1);
+    n.f32.rgb = add(D + 3, W / 2, 3);
+}
+
+int64_t algo_flops(const NetState& n) {   // 2 x MACs of nerf_model.py:53-76
+    int64_t mac = (int64_t)n.in_xyz * n.W;
+    for (int i = 1; i < n.D; ++i) mac += (int64_t)(i == n.skip + 1 ? n.W + n.in_xyz : n.W) * n.W;
+    mac += n.W /*alpha*/ + (int64_t)n.W * n.W /*feature*/ + (int64_t)(n.W + n.in_dir) * (n.W / 2) + (int64_t)(n.W / 2) * 3;
+    return 2 * mac;
+}
+
+__global__ void to8b_kernel(const float* __restrict__ x, uint8_t* __restrict__ y, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {   // model_utils.py:9: (255 * clip(x, 0, 1)).astype(uint8) -- truncation
+        const float v = 255.f * fminf(fmaxf(x[i], 0.f), 1.f);
+        y[i] = (uint8_t)(int)v;
+    }
+}
+
+int check_ready(nwe_ctx* ctx, const nwe_outputs* out, int precision) {
+    if (!ctx || !out) return fail(ctx, NWE_ERR_INVALID, "null context or outputs");
+    if (ctx->host_only) return fail(ctx, NWE_ERR_STATE, "host-only context cannot render");
+    if (ctx->ns <= 0) return fail(ctx, NWE_ERR_STATE, "nwe_set_sampling has not been called");
+    if (!ctx->net[0].set) return fail(ctx, NWE_ERR_STATE, "coarse network not set");
+    if (ctx->ni > 0 && !ctx->net[1].set) return fail(ctx, NWE_ERR_STATE, "fine network not set but n_importance > 0");
+    if (precision != NWE_PREC_F16X3 && precision != NWE_PREC_F16X1 && precision != NWE_PREC_F32)
+        return fail(ctx, NWE_ERR_INVALID, "unknown precision");
+    if (precision != NWE_PREC_F32) {
+        if (!ctx->net[0].mfma_ok || (ctx->ni > 0 && !ctx->net[1].mfma_ok))
+            return fail(ctx, NWE_ERR_UNSUPPORTED,
+                        "no MFMA kernel for this network shape (have 8x256 skip 4 and 4x128, 63/27 inputs); use NWE_PREC_F32");
+    }
+    return NWE_OK;
+}
+
+int launch(nwe_ctx* ctx, RenderArgs& a, int precision, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    a.t_vals = ctx->d_t; a.omt_vals = ctx->d_omt; a.u_vals = ctx->d_u;
+    a.n_samples = ctx->ns; a.n_importance = ctx->ni;
+    if (a.n_rays <= 0) return NWE_OK;
+    HIPCHK(ctx, hipEventRecord(ctx->ev0, stream));
+    if (precision == NWE_PREC_F32) {
+        launch_render_f32(a, ctx->net[0].f32, ctx->net[ctx->ni > 0 ? 1 : 0].f32, stream);
+    } else {
+        if (!launch_render_mfma(a, ctx->net[0].mf, ctx->net[ctx->ni > 0 ? 1 : 0].mf, precision == NWE_PREC_F16X3, stream))
+            return fail(ctx, NWE_ERR_UNSUPPORTED, "coarse and fine networks must have the same shape for the MFMA kernel");
+    }
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipEventRecord(ctx->ev1, stream));
+    ctx->timed = true;
+    return NWE_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int nwe_create(nwe_ctx** out, int device) {
+    if (!out) return fail(nullptr, NWE_ERR_INVALID, "out is null");
+    nwe_ctx* c = new nwe_ctx();
+    c->device = device;
+    c->host_only = device < 0;
+    if (!c->host_only) {
+        hipError_t e = hipSetDevice(device);
+        if (e == hipSuccess) e = hipEventCreate(&c->ev0);
+        if (e == hipSuccess) e = hipEventCreate(&c->ev1);
+        if (e != hipSuccess) {
+            g_create_error = std::string("nwe_create: ") + hipGetErrorString(e);
+            delete c;
+            return NWE_ERR_HIP;
+        }
+    }
+    *out = c;
+    return NWE_OK;
+}
+
+void nwe_destroy(nwe_ctx* c) {
+    if (!c) return;
+    if (!c->host_only) {
+        (void)hipSetDevice(c->device);
+        for (NetState& n : c->net) { if (n.d_blob) (void)hipFree(n.d_blob); if (n.d_stream) (void)hipFree(n.d_stream); }
+        if (c->d_t) (void)hipFree(c->d_t);
+        if (c->d_poses) (void)hipFree(c->d_poses);
+        if (c->ev0) (void)hipEventDestroy(c->ev0);
+        if (c->ev1) (void)hipEventDestroy(c->ev1);
+    }
+    delete c;
+}
+
+const char* nwe_last_error(const nwe_ctx* c) { return c ? c->err.c_str() : g_create_error.c_str(); }
+
+int nwe_set_network(nwe_ctx* c, int which, int depth, int width, int in_xyz, int in_dir, int skip_layer,
+                    const float* const* w, const float* const* b) {
+    if (!c || !w || !b) return fail(c, NWE_ERR_INVALID, "null argument");
+    if (which != NWE_NET_COARSE && which != NWE_NET_FINE) return fail(c, NWE_ERR_INVALID, "which must be 0 or 1");
+    if (depth < 1 || depth > kMaxDepth) return fail(c, NWE_ERR_UNSUPPORTED, "depth must be in 1..16");
+    if (width < 2 || width > 256 || width % 2) return fail(c, NWE_ERR_UNSUPPORTED, "width must be even and <= 256");
+    if (in_xyz < 3 || in_xyz > 93 || (in_xyz - 3) % 6 || in_dir < 3 || in_dir > 63 || (in_dir - 3) % 6)
+        return fail(c, NWE_ERR_UNSUPPORTED, "encoded widths must be 3 + 6*num_freqs (xyz <= 93, dir <= 63)");
+    if (skip_layer < -1 || skip_layer >= depth - 1) skip_layer = -1;   // a skip after the last trunk layer never feeds a layer
+    for (int i = 0; i < depth + 4; ++i)
+        if (!w[i] || !b[i]) return fail(c, NWE_ERR_INVALID, "null weight or bias pointer");
+    NetState& n = c->net[which];
+    n.D = depth; n.W = width; n.in_xyz = in_xyz; n.in_dir = in_dir; n.skip = skip_layer;
+    n.flops = algo_flops(n);
+    pack_f32(n, w, b);
+    n.mfma_ok = mfma_supported(depth, width, in_xyz, in_dir, skip_layer);
+    if (n.mfma_ok) pack_mfma(n, w, b); else n.stream.clear();
+    n.mf = {};
+    n.mf.D = depth; n.mf.W = width; n.mf.skip = skip_layer; n.mf.n_tiles = (int)(n.stream.size() / kTileBytes);
+    if (!c->host_only) {
+        HIPCHK(c, hipSetDevice(c->device));
+        if (n.d_blob) { (void)hipFree(n.d_blob); n.d_blob = nullptr; }
+        if (n.d_stream) { (void)hipFree(n.d_stream); n.d_stream = nullptr; }
+        HIPCHK(c, hipMalloc(&n.d_blob, n.blob.size() * sizeof(float)));
+        HIPCHK(c, hipMemcpy(n.d_blob, n.blob.data(), n.blob.size() * sizeof(float), hipMemcpyHostToDevice));
+        if (n.mfma_ok) {
+            HIPCHK(c, hipMalloc(&n.d_stream, n.stream.size()));
+            HIPCHK(c, hipMemcpy(n.d_stream, n.stream.data(), n.stream.size(), hipMemcpyHostToDevice));
+        }
+        n.f32.blob = n.d_blob;
+        n.mf.stream = n.d_stream;
+    }
+    n.set = true;
+    return NWE_OK;
+}
+
+int nwe_set_sampling(nwe_ctx* c, const float* t_vals, const float* one_minus_t, int n_samples, const float* u,
+                     int n_importance) {
+    if (!c || !t_vals || !one_minus_t) return fail(c, NWE_ERR_INVALID, "null argument");
+    if (n_samples < 2 || n_samples > kMaxSamples) return fail(c, NWE_ERR_UNSUPPORTED, "n_samples must be in 2..128");
+    if (n_importance < 0 || n_importance > kMaxImportance) return fail(c, NWE_ERR_UNSUPPORTED, "n_importance must be in 0..256");
+    if (n_importance > 0 && (!u || n_samples < 3)) return fail(c, NWE_ERR_INVALID, "importance sampling needs u and n_samples >= 3");
+    c->ns = n_samples; c->ni = n_importance;
+    if (c->host_only) return NWE_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!c->d_t) {
+        HIPCHK(c, hipMalloc(&c->d_t, (2 * kMaxSamples + kMaxImportance) * sizeof(float)));
+        c->d_omt = c->d_t + kMaxSamples;
+        c->d_u = c->d_omt + kMaxSamples;
+    }
+    HIPCHK(c, hipMemcpy(c->d_t, t_vals, n_samples * sizeof(float), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->d_omt, one_minus_t, n_samples * sizeof(float), hipMemcpyHostToDevice));
+    if (n_importance > 0) HIPCHK(c, hipMemcpy(c->d_u, u, n_importance * sizeof(float), hipMemcpyHostToDevice));
+    return NWE_OK;
+}
+
+int nwe_render(nwe_ctx* c, const float* c2w, int n_poses, int H, int W, float fx, float fy, float cx, float cy, float near,
+               float far, int row_begin, int row_end, int precision, const nwe_outputs* out, void* stream) {
+    int rc = check_ready(c, out, precision);
+    if (rc) return rc;
+    if (!c2w || n_poses < 1 || H < 1 || W < 1 || row_begin < 0 || row_end > H || row_begin > row_end)
+        return fail(c, NWE_ERR_INVALID, "bad pose / image / row range");
+    if (!(fx != 0.f) || !(fy != 0.f)) return fail(c, NWE_ERR_INVALID, "fx and fy must be non-zero");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (n_poses > c->poses_cap) {
+        if (c->d_poses) (void)hipFree(c->d_poses);
+        c->poses_cap = std::max(n_poses, 64);
+        HIPCHK(c, hipMalloc(&c->d_poses, (size_t)c->poses_cap * 16 * sizeof(float)));
+    }
+    HIPCHK(c, hipMemcpyAsync(c->d_poses, c2w, (size_t)n_poses * 16 * sizeof(float), hipMemcpyHostToDevice, (hipStream_t)stream));
+    RenderArgs a = {};
+    a.rays = nullptr; a.poses = c->d_poses;
+    a.H = H; a.W = W; a.row_begin = row_begin; a.rows = row_end - row_begin;
+    a.n_rays = (int64_t)n_poses * a.rows * W;
+    a.fx = fx; a.fy = fy; a.cx = cx; a.cy = cy; a.near = near; a.far = far;
+    a.out = *out;
+    return launch(c, a, precision, stream);
+}
+
+int nwe_render_rays(nwe_ctx* c, const float* rays_dev, int64_t n_rays, int precision, const nwe_outputs* out, void* stream) {
+    int rc = check_ready(c, out, precision);
+    if (rc) return rc;
+    if (!rays_dev || n_rays < 0) return fail(c, NWE_ERR_INVALID, "bad rays");
+    HIPCHK(c, hipSetDevice(c->device));
+    RenderArgs a = {};
+    a.rays = rays_dev; a.n_rays = n_rays; a.W = 1; a.rows = 1;
+    a.out = *out;
+    return launch(c, a, precision, stream);
+}
+
+int nwe_to8b(nwe_ctx* c, const float* rgb_dev, uint8_t* out_dev, int64_t n, void* stream) {
+    if (!c || c->host_only || !rgb_dev || !out_dev || n < 0) return fail(c, NWE_ERR_INVALID, "bad argument");
+    if (n == 0) return NWE_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    hipLaunchKernelGGL(to8b_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, rgb_dev, out_dev, n);
+    HIPCHK(c, hipGetLastError());
+    return NWE_OK;
+}
+
+int64_t nwe_flops_per_eval(const nwe_ctx* c, int which) {
+    if (!c || which < 0 || which > 1 || !c->net[which].set) return 0;
+    return c->net[which].flops;
+}
+
+float nwe_last_kernel_ms(nwe_ctx* c) {
+    if (!c || c->host_only || !c->timed) return -1.f;
+    if (hipEventSynchronize(c->ev1) != hipSuccess) return -1.f;
+    float ms = -1.f;
+    if (hipEventElapsedTime(&ms, c->ev0, c->ev1) != hipSuccess) return -1.f;
+    return ms;
+}
+
+int64_t nwe_packed_bytes(const nwe_ctx* c, int which) {
+    if (!c || which < 0 || which > 1 || !c->net[which].set) return 0;
+    return (int64_t)c->net[which].stream.size();
+}
+
+int nwe_packed_copy(const nwe_ctx* c, int which, void* host_dst, int64_t bytes) {
+    if (!c || which < 0 || which > 1 || !host_dst || !c->net[which].set) return NWE_ERR_INVALID;
+    if (bytes != (int64_t)c->net[which].stream.size()) return NWE_ERR_INVALID;
+    std::memcpy(host_dst, c->net[which].stream.data(), (size_t)bytes);
+    return NWE_OK;
+}
+
+int nwe_selftest(nwe_ctx* c, int32_t* report8) {
+    if (!c || c->host_only || !report8) return fail(c, NWE_ERR_INVALID, "bad argument");
+    HIPCHK(c, hipSetDevice(c->device));
+    const int rc = run_selftest(report8, nullptr);
+    if (rc == -1) return fail(c, NWE_ERR_HIP, "selftest: HIP failure");
+    if (rc != 0) return fail(c, NWE_ERR_STATE, "selftest: a hardware layout assumption does not hold (see report)");
+    return NWE_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,203 @@
+// Device-side building blocks shared by the fp32 and the MFMA render kernels: ray set-up, coarse
+// depths, front-to-back compositing, inverse-CDF fine sampling with the sorted merge.
+//
+// Every formula follows the reference's op ORDER (file:line relative to the reference root), because
+// the top positional-encoding band multiplies a point coordinate by 2^9/10: one fp32 ulp of the point
+// is ~5e-5 rad there (SURVEY.md §7 hard part 3).  Hence: no FMA contraction where torch rounds twice
+// (this translation unit is compiled with -ffp-contract=off and uses __f*_rn where it matters), true
+// divisions, and the fp64 running product/sum that torch's CPU cumprod/cumsum use (measured: their
+// accumulator is double, rounded to float at every element).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/nwe.h"
+
+namespace nwe {
+
+constexpr int kMaxSamples = 128;     // n_samples upper bound (LDS tables)
+constexpr int kMaxImportance = 256;  // n_importance upper bound
+
+// Kernel arguments common to both kernels (passed by value).
+struct RenderArgs {
+    // ray source: either precomputed rays [n_rays,11] or pinhole poses
+    const float* rays;       // device, may be null -> generate from poses
+    const float* poses;      // device, n_poses x 16 (row-major c2w)
+    int64_t n_rays;          // total rays of the call
+    int H, W, row_begin, rows;  // rows = row_end-row_begin; rays per pose = rows*W
+    float fx, fy, cx, cy, near, far;
+    // sampling tables (device): t[ns], 1-t[ns], u[ni]
+    const float* t_vals;
+    const float* omt_vals;
+    const float* u_vals;
+    int n_samples, n_importance;
+    nwe_outputs out;
+};
+
+struct Ray {
+    float ox, oy, oz, dx, dy, dz, near, far, vx, vy, vz, dnorm;
+};
+
+// sqrt(x^2+y^2+z^2) exactly as torch.norm(dim=-1) evaluates a 3-vector on CPU: an FMA chain over the
+// elements in order (measured bit-exact on 20k vectors), correctly rounded sqrt.
+__device__ __forceinline__ float norm3(float x, float y, float z) {
+    return __fsqrt_rn(__fmaf_rn(z, z, __fmaf_rn(y, y, __fmul_rn(x, x))));
+}
+
+// nerf/rays/rays.py:6-71.  idx is the ray index inside the call.
+__device__ __forceinline__ Ray load_ray(const RenderArgs& a, int64_t idx) {
+    Ray r;
+    if (a.rays) {  // handler.py:210-214: columns [o d near far viewdir]
+        const float* p = a.rays + idx * 11;
+        r.ox = p[0]; r.oy = p[1]; r.oz = p[2];
+        r.dx = p[3]; r.dy = p[4]; r.dz = p[5];
+        r.near = p[6]; r.far = p[7];
+        r.vx = p[8]; r.vy = p[9]; r.vz = p[10];
+    } else {
+        const int per_pose = a.rows * a.W;
+        const int pose = (int)(idx / per_pose);
+        const int rem = (int)(idx - (int64_t)pose * per_pose);
+        const int h = a.row_begin + rem / a.W, w = rem % a.W;
+        const float* m = a.poses + pose * 16;
+        // rays.py:52-56: ((w-cx)/fx, (h-cy)/fy, 1), true divisions
+        const float x = __fdiv_rn(__fsub_rn((float)w, a.cx), a.fx);
+        const float y = __fdiv_rn(__fsub_rn((float)h, a.cy), a.fy);
+        // rays.py:67: 3x3 @ 3x1 as torch's CPU bmm does it: products summed left to right, no FMA
+        r.dx = __fadd_rn(__fadd_rn(__fmul_rn(m[0], x), __fmul_rn(m[1], y)), m[2]);
+        r.dy = __fadd_rn(__fadd_rn(__fmul_rn(m[4], x), __fmul_rn(m[5], y)), m[6]);
+        r.dz = __fadd_rn(__fadd_rn(__fmul_rn(m[8], x), __fmul_rn(m[9], y)), m[10]);
+        r.ox = m[3]; r.oy = m[7]; r.oz = m[11];          // rays.py:68
+        r.near = a.near; r.far = a.far;                  // rays.py:26
+        const float n = norm3(r.dx, r.dy, r.dz);         // rays.py:24
+        r.vx = __fdiv_rn(r.dx, n); r.vy = __fdiv_rn(r.dy, n); r.vz = __fdiv_rn(r.dz, n);
+    }
+    r.dnorm = norm3(r.dx, r.dy, r.dz);                   // model_utils.py:60
+    return r;
+}
+
+// handler.py:218: near*(1-t) + far*t, two products and one sum
+__device__ __forceinline__ float coarse_z(const Ray& r, float t, float omt) {
+    return __fadd_rn(__fmul_rn(r.near, omt), __fmul_rn(r.far, t));
+}
+
+// handler.py:223 / :246: o + d*z, product then sum (no FMA)
+__device__ __forceinline__ void point_at(const Ray& r, float z, float& px, float& py, float& pz) {
+    px = __fadd_rn(r.ox, __fmul_rn(r.dx, z));
+    py = __fadd_rn(r.oy, __fmul_rn(r.dy, z));
+    pz = __fadd_rn(r.oz, __fmul_rn(r.dz, z));
+}
+
+// Front-to-back alpha compositing of one ray, one sample per step.  nerf/models/model_utils.py:49-100.
+struct Composite {
+    double t_run;  // running product of (1-alpha+1e-10), fp64 like torch's CPU cumprod (:79)
+    float r, g, b, depth, acc;
+    __device__ __forceinline__ void reset() {
+        t_run = 1.0; r = g = b = depth = acc = 0.f;
+    }
+    // raw = network output for this sample, z = its depth, z_next = next depth (ignored when last).
+    // Returns the sample's weight (alpha * transmittance).
+    __device__ __forceinline__ float step(float raw_r, float raw_g, float raw_b, float raw_s, float z, float z_next,
+                                          bool last, float dnorm) {
+        float dist = last ? 1e10f : __fsub_rn(z_next, z);                    // :51-56
+        dist = __fmul_rn(dist, dnorm);                                       // :60
+        const float sig = fmaxf(raw_s, 0.f);                                 // relu, :49
+        const float alpha = __fsub_rn(1.f, expf(-__fmul_rn(sig, dist)));     // :49
+        const float w = __fmul_rn(alpha, (float)t_run);                      // :79-80 (cumprod shifted by one)
+        t_run *= (double)__fadd_rn(__fsub_rn(1.f, alpha), 1e-10f);
+        const float cr = __fdiv_rn(1.f, __fadd_rn(1.f, expf(-raw_r)));       // sigmoid, :62
+        const float cg = __fdiv_rn(1.f, __fadd_rn(1.f, expf(-raw_g)));
+        const float cb = __fdiv_rn(1.f, __fadd_rn(1.f, expf(-raw_b)));
+        r = __fadd_rn(r, __fmul_rn(w, cr));                                  // :84
+        g = __fadd_rn(g, __fmul_rn(w, cg));
+        b = __fadd_rn(b, __fmul_rn(w, cb));
+        depth = __fadd_rn(depth, __fmul_rn(w, z));                           // :93
+        acc = __fadd_rn(acc, w);                                             // :95
+        return w;
+    }
+    // :94  1 / max(1e-10, depth/acc); torch.max propagates NaN (acc == 0 -> NaN)
+    __device__ __forceinline__ float disp() const {
+        const float q = __fdiv_rn(depth, acc);
+        const float m = (q != q) ? q : fmaxf(1e-10f, q);
+        return __fdiv_rn(1.f, m);
+    }
+};
+
+// Inverse-CDF importance sampling merged with the coarse depths, one depth per call in sorted order.
+// nerf/rays/rays.py:74-121 (det=True) + handler.py:236-243.  The coarse depths and the importance
+// samples are each already sorted, so torch.sort(cat(...)) is a two-way merge of the same values.
+// `wc` points at this ray's coarse weights in LDS, element i at wc[i*stride]; prepare() overwrites
+// elements 0..ns-2 with the cdf (rays.py:87-90).
+struct FineSampler {
+    float* wc; int stride;
+    const float* t_tab; const float* omt_tab; const float* u_tab;   // LDS tables
+    int ns, ni;
+    int ci, fj, ptr;
+    float cur_f;
+    double s1, s2;   // sum / sum of squares of the importance samples (z_std, handler.py:267)
+
+    __device__ __forceinline__ float zc(const Ray& r, int i) const { return coarse_z(r, t_tab[i], omt_tab[i]); }
+    __device__ __forceinline__ float zmid(const Ray& r, int k) const {       // handler.py:236
+        return __fmul_rn(.5f, __fadd_rn(zc(r, k + 1), zc(r, k)));
+    }
+    __device__ __forceinline__ void prepare(const Ray& r) {
+        // weights[..., 1:-1] + 1e-5, normalised, cumulative (double accumulator, float per element)
+        float sum = 0.f;
+        for (int i = 1; i < ns - 1; ++i) sum = __fadd_rn(sum, __fadd_rn(wc[i * stride], 1e-5f));
+        double run = 0.0;
+        wc[0] = 0.f;                                                         // rays.py:90 leading zero
+        for (int i = 1; i < ns - 1; ++i) {                                   // cdf[i] replaces weight i in place
+            run += (double)__fdiv_rn(__fadd_rn(wc[i * stride], 1e-5f), sum);
+            wc[i * stride] = (float)run;
+        }
+        ci = 0; fj = 0; ptr = 0; s1 = 0.0; s2 = 0.0;
+        cur_f = sample(r, 0);
+    }
+    // importance sample j (u ascending, so the searchsorted position only moves forward)
+    __device__ __forceinline__ float sample(const Ray& r, int j) {
+        const int ncdf = ns - 1;
+        const float u = u_tab[j];
+        while (ptr < ncdf && wc[ptr * stride] <= u) ++ptr;                   // searchsorted(right=True), :103
+        const int below = max(ptr - 1, 0), above = min(ptr, ncdf - 1);       // :104-105
+        const float cb = wc[below * stride], ca = wc[above * stride];
+        const float bb = zmid(r, below), ba = zmid(r, above);
+        float denom = __fsub_rn(ca, cb);                                     // :113
+        if (denom < 1e-5f) denom = 1.f;
+        const float t = __fdiv_rn(__fsub_rn(u, cb), denom);                  // :118
+        const float z = __fadd_rn(bb, __fmul_rn(t, __fsub_rn(ba, bb)));      // :119
+        s1 += (double)z; s2 += (double)z * (double)z;
+        return z;
+    }
+    __device__ __forceinline__ float next(const Ray& r) {
+        const float a = ci < ns ? zc(r, ci) : INFINITY;
+        const float f = fj < ni ? cur_f : INFINITY;
+        if (!(fj < ni) || a <= f) { ++ci; return a; }
+        ++fj;
+        if (fj < ni) cur_f = sample(r, fj);
+        return f;
+    }
+    __device__ __forceinline__ float z_std() const {                         // unbiased=False
+        const double m = s1 / ni, v = s2 / ni - m * m;
+        return (float)sqrt(v > 0.0 ? v : 0.0);
+    }
+};
+
+__device__ __forceinline__ bool bad(float x) { return !(fabsf(x) <= 3.402823466e38f); }  // NaN or inf
+
+// Writes the per-ray results of one pass into the fine (handler.py:263-266) or coarse (:257-260) slots
+// and returns the NaN/Inf flag bits of what it wrote (handler.py:273-275).
+__device__ __forceinline__ uint32_t store_ray(const nwe_outputs& o, int64_t idx, const Composite& c, bool fine) {
+    const float d = c.disp();
+    float* rgb = fine ? o.rgb : o.rgb_coarse;
+    float* depth = fine ? o.depth : o.depth_coarse;
+    float* acc = fine ? o.acc : o.acc_coarse;
+    float* disp = fine ? o.disp : o.disp_coarse;
+    if (rgb) { rgb[idx * 3] = c.r; rgb[idx * 3 + 1] = c.g; rgb[idx * 3 + 2] = c.b; }
+    if (depth) depth[idx] = c.depth;
+    if (acc) acc[idx] = c.acc;
+    if (disp) disp[idx] = d;
+    const uint32_t f = ((bad(c.r) || bad(c.g) || bad(c.b)) ? NWE_FLAG_RGB : 0) | (bad(c.depth) ? NWE_FLAG_DEPTH : 0) |
+                       (bad(c.acc) ? NWE_FLAG_ACC : 0) | (bad(d) ? NWE_FLAG_DISP : 0);
+    return fine ? f : (f << 4);   // the coarse flag bits sit 4 above the fine ones
+}
+
+}  // namespace nwe

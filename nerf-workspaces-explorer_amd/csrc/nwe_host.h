@@ -1,0 +1,43 @@
+// Host/device shared descriptors of the two render kernels and their launchers.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "nwe_device.h"
+
+namespace nwe {
+
+// ---- fp32 kernel: transposed weights Wt[k][n] + bias in one float blob ------------------------
+struct LayerF32 {
+    int K, N;
+    int64_t wt_off, b_off;  // float offsets into the blob
+};
+struct NetF32 {
+    const float* blob;
+    int D, W, in_xyz, in_dir, skip;
+    LayerF32 pts[16];
+    LayerF32 views, feature, alpha, rgb;
+};
+constexpr int kMaxDepth = 16;
+
+void launch_render_f32(const RenderArgs& a, const NetF32& nc, const NetF32& nf, hipStream_t stream);
+
+// ---- MFMA kernel: a stream of 1-KiB tiles in consumption order (DESIGN.md "weight stream") -----
+struct NetMfma {
+    const uint8_t* stream;  // device
+    int n_tiles;
+    int D, W, skip;
+};
+
+// true if a kernel instantiation exists for this shape
+bool mfma_supported(int D, int W, int in_xyz, int in_dir, int skip);
+// returns false if the shape has no instantiation
+bool launch_render_mfma(const RenderArgs& a, const NetMfma& nc, const NetMfma& nf, bool three_pass, hipStream_t stream);
+
+constexpr int kTileBytes = 1024;
+constexpr int kLoShift = 11;  // lo halves are stored as (x - hi) * 2^11 so they stay fp16-normal
+
+// Self-test kernels (nwe_selftest.hip)
+int run_selftest(int32_t* report8, hipStream_t stream);
+
+}  // namespace nwe

@@ -1,0 +1,130 @@
+// Device self-test of the gfx950 behaviours the MFMA render kernel is built on.  Exact small-integer
+// data, asymmetric operands (a symmetric B hides a transposed C write).
+//   report[0]  mismatches of v_mfma_f32_32x32x16_f16 against the assumed A/B/D lane maps
+//   report[1]  mismatches when a 32x32 accumulator tile is reused as the next B operand with the
+//              packer's k permutation (hidden_col)
+//   report[2]  1 if fp16 subnormal MFMA operands are honoured, 0 if flushed to zero (informational)
+//   report[3]  mismatches of the LDS-DMA (global_load_lds_dwordx4) lane order: LDS[base + 16*lane]
+//   report[4]  max |sincosf - fp64| over arguments up to 1.1e3 rad, in units of 1e-9 (informational)
+//   report[5]  max relative error of expf over [-20, 20], in units of 1e-9 (informational)
+#include <cmath>
+#include <vector>
+
+#include "nwe_host.h"
+
+namespace nwe {
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef float f16v __attribute__((ext_vector_type(16)));
+
+__host__ __device__ inline int tA(int i, int k) { return ((i * 3 + k * 5) % 7) - 3; }
+__host__ __device__ inline int tB(int k, int n) { return ((k * 2 + n * 7) % 5) - 2; }
+__host__ __device__ inline int tA2(int i, int f) { return ((i + 2 * f) % 5) - 2; }
+__host__ __device__ inline int hidden_col_d(int s, int h, int j) { return 16 * s + 8 * (j >> 2) + 4 * h + (j & 3); }
+
+__global__ void selftest_kernel(float* d1 /*32x32*/, float* d2 /*32x32*/, float* sub, const uint32_t* pattern,
+                                uint32_t* lds_out /*2 x 256 words*/, const float* args, float* sc /*2n*/, float* ex, int n) {
+    __shared__ __attribute__((aligned(16))) uint32_t s_buf[512];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 31, h = lane >> 5;
+    if (wave == 0) {
+        h8 a, b;
+        for (int j = 0; j < 8; ++j) { a[j] = (_Float16)tA(i, 8 * h + j); b[j] = (_Float16)tB(8 * h + j, i); }
+        f16v acc;
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc, 0, 0, 0);
+        for (int r = 0; r < 16; ++r) d1[((r & 3) + 8 * (r >> 2) + 4 * h) * 32 + i] = acc[r];
+        // accumulator tile -> B operand of two k-steps
+        f16v acc2;
+        for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
+        for (int s = 0; s < 2; ++s) {
+            h8 a2, b2;
+            for (int j = 0; j < 8; ++j) { a2[j] = (_Float16)tA2(i, hidden_col_d(s, h, j)); b2[j] = (_Float16)acc[8 * s + j]; }
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2, b2, acc2, 0, 0, 0);
+        }
+        for (int r = 0; r < 16; ++r) d2[((r & 3) + 8 * (r >> 2) + 4 * h) * 32 + i] = acc2[r];
+        // subnormal operands
+        h8 sa, sb;
+        for (int j = 0; j < 8; ++j) { sa[j] = (_Float16)9.5367431640625e-07f; sb[j] = (_Float16)1024.f; }
+        f16v acc3;
+        for (int r = 0; r < 16; ++r) acc3[r] = 0.f;
+        acc3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(sa, sb, acc3, 0, 0, 0);
+        if (lane == 0) sub[0] = acc3[0];
+    }
+    // LDS-DMA: wave w copies tile w (1 KiB) with a per-lane source and a wave-uniform destination
+    if (wave < 2) {
+        const char* src = reinterpret_cast<const char*>(pattern) + wave * 1024 + lane * 16;
+        char* dst = reinterpret_cast<char*>(s_buf) + wave * 1024;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int k = threadIdx.x; k < 512; k += blockDim.x) lds_out[k] = s_buf[k];
+    for (int k = threadIdx.x; k < n; k += blockDim.x) {
+        float sn, cs;
+        sincosf(args[k], &sn, &cs);
+        sc[2 * k] = sn; sc[2 * k + 1] = cs;
+        ex[k] = expf(-20.f + 40.f * (float)k / (float)n);
+    }
+}
+
+#define ST_CHK(x) do { if ((x) != hipSuccess) return -1; } while (0)
+
+int run_selftest(int32_t* rep, hipStream_t stream) {
+    for (int k = 0; k < 8; ++k) rep[k] = 0;
+    const int n = 4096;
+    std::vector<float> args(n);
+    for (int k = 0; k < n; ++k) {   // gamma(x) arguments: v*2^b with |v| <= 2.2, b <= 9
+        const double v = -2.2 + 4.4 * ((k * 2654435761u) % 100003) / 100003.0;
+        args[k] = (float)v * (float)(1 << (k % 10));
+    }
+    std::vector<uint32_t> pat(512);
+    for (int k = 0; k < 512; ++k) pat[k] = 0x9e3779b9u * (k + 1);
+    float *d1, *d2, *sub, *dargs, *sc, *ex; uint32_t *dpat, *dlds;
+    ST_CHK(hipMalloc(&d1, 4096)); ST_CHK(hipMalloc(&d2, 4096)); ST_CHK(hipMalloc(&sub, 16));
+    ST_CHK(hipMalloc(&dargs, n * 4)); ST_CHK(hipMalloc(&sc, n * 8)); ST_CHK(hipMalloc(&ex, n * 4));
+    ST_CHK(hipMalloc(&dpat, 2048)); ST_CHK(hipMalloc(&dlds, 2048));
+    ST_CHK(hipMemcpy(dargs, args.data(), n * 4, hipMemcpyHostToDevice));
+    ST_CHK(hipMemcpy(dpat, pat.data(), 2048, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(selftest_kernel, dim3(1), dim3(256), 0, stream, d1, d2, sub, dpat, dlds, dargs, sc, ex, n);
+    ST_CHK(hipGetLastError());
+    ST_CHK(hipStreamSynchronize(stream));
+    std::vector<float> h1(1024), h2(1024), hsc(2 * n), hex(n); float hsub = -1.f; std::vector<uint32_t> hl(512);
+    ST_CHK(hipMemcpy(h1.data(), d1, 4096, hipMemcpyDeviceToHost));
+    ST_CHK(hipMemcpy(h2.data(), d2, 4096, hipMemcpyDeviceToHost));
+    ST_CHK(hipMemcpy(&hsub, sub, 4, hipMemcpyDeviceToHost));
+    ST_CHK(hipMemcpy(hl.data(), dlds, 2048, hipMemcpyDeviceToHost));
+    ST_CHK(hipMemcpy(hsc.data(), sc, n * 8, hipMemcpyDeviceToHost));
+    ST_CHK(hipMemcpy(hex.data(), ex, n * 4, hipMemcpyDeviceToHost));
+    for (void* p : {(void*)d1, (void*)d2, (void*)sub, (void*)dargs, (void*)sc, (void*)ex, (void*)dpat, (void*)dlds}) (void)hipFree(p);
+
+    std::vector<int> X(1024);
+    for (int i = 0; i < 32; ++i)
+        for (int c = 0; c < 32; ++c) {
+            int s = 0;
+            for (int k = 0; k < 16; ++k) s += tA(i, k) * tB(k, c);
+            X[i * 32 + c] = s;
+            if (h1[i * 32 + c] != (float)s) rep[0]++;
+        }
+    for (int i = 0; i < 32; ++i)
+        for (int c = 0; c < 32; ++c) {
+            int s = 0;
+            for (int f = 0; f < 32; ++f) s += tA2(i, f) * X[f * 32 + c];
+            if (h2[i * 32 + c] != (float)s) rep[1]++;
+        }
+    rep[2] = hsub == 0.015625f ? 1 : (hsub == 0.f ? 0 : -1);
+    for (int k = 0; k < 512; ++k) if (hl[k] != pat[k]) rep[3]++;
+    double worst = 0.0, worst_e = 0.0;
+    for (int k = 0; k < n; ++k) {
+        worst = std::fmax(worst, std::fabs((double)hsc[2 * k] - std::sin((double)args[k])));
+        worst = std::fmax(worst, std::fabs((double)hsc[2 * k + 1] - std::cos((double)args[k])));
+        const double x = (double)(-20.f + 40.f * (float)k / (float)n);
+        worst_e = std::fmax(worst_e, std::fabs((double)hex[k] - std::exp(x)) / std::exp(x));
+    }
+    rep[4] = (int32_t)(worst * 1e9);
+    rep[5] = (int32_t)(worst_e * 1e9);
+    return (rep[0] == 0 && rep[1] == 0 && rep[3] == 0) ? 0 : 1;
+}
+
+}  // namespace nwe

@@ -1,0 +1,193 @@
+"""Thin host wrapper over the C ABI (include/nwe.h): owns one ``nwe_ctx``, allocates the output tensors
+with torch (device memory and streams only) and hands raw pointers to the HIP library.
+
+No arithmetic of the render path happens here; if ``libnwe_hip.so`` is missing every entry point raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Iterable, Mapping, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+
+LAYER_ORDER_TAIL = ("_views_linears.0", "_feature_linear", "_alpha_linear", "_rgb_linear")
+
+_PER_RAY = {"rgb": 3, "depth": 1, "acc": 1, "disp": 1, "z_std": 1, "rgb_coarse": 3, "depth_coarse": 1,
+            "acc_coarse": 1, "disp_coarse": 1}
+
+
+def normalize_state_dict(sd: Mapping[str, object]) -> Dict[str, np.ndarray]:
+    """Accept both spellings of the reference's keys: checkpoints carry ``pts_linears.0.weight``, the
+    current modules ``_pts_linears.0.weight`` (nerf_replica_inference_handler.py:150-164)."""
+    out = {}
+    for k, v in sd.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        v = np.ascontiguousarray(np.asarray(v, dtype=np.float32))
+        out[k if k.startswith("_") else "_" + k] = v
+    return out
+
+
+def net_shape(sd: Mapping[str, np.ndarray]) -> Tuple[int, int, int, int, int]:
+    """(D, W, in_xyz, in_dir, skip_layer) from the tensor shapes (nerf/models/nerf_model.py:32-43)."""
+    D = 0
+    while f"_pts_linears.{D}.weight" in sd:
+        D += 1
+    if D == 0:
+        raise ValueError("state dict has no _pts_linears.0.weight")
+    W, in_xyz = sd["_pts_linears.0.weight"].shape
+    in_dir = sd["_views_linears.0.weight"].shape[1] - W
+    skip = -1
+    for i in range(1, D):
+        k = sd[f"_pts_linears.{i}.weight"].shape[1]
+        if k == W + in_xyz:
+            if skip != -1:
+                raise ValueError("more than one skip connection is not supported")
+            skip = i - 1
+        elif k != W:
+            raise ValueError(f"_pts_linears.{i}.weight has unexpected input width {k}")
+    return D, int(W), int(in_xyz), int(in_dir), skip
+
+
+class Renderer:
+    """One HIP context on one GPU.  Not thread-safe (like the reference handler)."""
+
+    def __init__(self, device: int = 0, host_only: bool = False):
+        self._lib = _lib.load()
+        self._ctx = C.c_void_p()
+        self.device_index = -1 if host_only else int(device)
+        rc = self._lib.nwe_create(C.byref(self._ctx), self.device_index)
+        if rc != _lib.NWE_OK:
+            raise RuntimeError(f"nwe_create failed: {self._lib.nwe_last_error(None).decode()}")
+        self.device = None if host_only else torch.device("cuda", self.device_index)
+        self.n_samples = 0
+        self.n_importance = 0
+        self.shapes: Dict[int, Tuple[int, int, int, int, int]] = {}
+
+    def close(self) -> None:
+        if getattr(self, "_ctx", None) is not None and self._ctx.value:
+            self._lib.nwe_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc: int, what: str) -> None:
+        if rc != _lib.NWE_OK:
+            msg = self._lib.nwe_last_error(self._ctx).decode()
+            exc = NotImplementedError if rc == _lib.NWE_ERR_UNSUPPORTED else (ValueError if rc == _lib.NWE_ERR_INVALID else RuntimeError)
+            raise exc(f"{what}: {msg}")
+
+    # -- set-up -----------------------------------------------------------------------------------
+    def set_network(self, which: int, state_dict: Mapping[str, object]) -> Tuple[int, int, int, int, int]:
+        sd = normalize_state_dict(state_dict)
+        D, W, in_xyz, in_dir, skip = net_shape(sd)
+        names = [f"_pts_linears.{i}" for i in range(D)] + list(LAYER_ORDER_TAIL)
+        ws = [sd[n + ".weight"] for n in names]
+        bs = [sd[n + ".bias"] for n in names]
+        expect_in = [in_xyz] + [W + in_xyz if i - 1 == skip else W for i in range(1, D)] + [W + in_dir, W, W, W // 2]
+        expect_out = [W] * D + [W // 2, W, 1, 3]
+        for n, w, b, ki, ko in zip(names, ws, bs, expect_in, expect_out):
+            if w.shape != (ko, ki) or b.shape != (ko,):
+                raise ValueError(f"{n}: expected weight [{ko},{ki}] and bias [{ko}], got {w.shape} / {b.shape}")
+        wp = (C.c_void_p * len(ws))(*[w.ctypes.data for w in ws])
+        bp = (C.c_void_p * len(bs))(*[b.ctypes.data for b in bs])
+        self._check(self._lib.nwe_set_network(self._ctx, which, D, W, in_xyz, in_dir, skip, wp, bp), "nwe_set_network")
+        self.shapes[which] = (D, W, in_xyz, in_dir, skip)
+        return self.shapes[which]
+
+    def set_sampling(self, n_samples: int, n_importance: int) -> None:
+        """Tables come from torch.linspace on the host, whose bits differ from i/(n-1)."""
+        t = torch.linspace(0., 1., steps=n_samples)                    # handler.py:216
+        omt = 1. - t                                                   # handler.py:218
+        u = torch.linspace(0., 1., steps=max(n_importance, 1))         # nerf/rays/rays.py:95
+        self._check(self._lib.nwe_set_sampling(self._ctx, t.numpy().ctypes.data, omt.numpy().ctypes.data, n_samples,
+                                               u.numpy().ctypes.data if n_importance > 0 else None, n_importance),
+                    "nwe_set_sampling")
+        self.n_samples, self.n_importance = n_samples, n_importance
+
+    # -- rendering --------------------------------------------------------------------------------
+    def _alloc(self, n_rays: int, outputs: Iterable[str]) -> Tuple[_lib.Outputs, Dict[str, torch.Tensor]]:
+        res: Dict[str, torch.Tensor] = {}
+        S = self.n_samples + self.n_importance
+        for name in outputs:
+            if name in _PER_RAY:
+                shape = (n_rays, 3) if _PER_RAY[name] == 3 else (n_rays,)
+            elif name == "raw_coarse":
+                shape = (n_rays, self.n_samples, 4)
+            elif name == "raw_fine":
+                shape = (n_rays, S, 4)
+            elif name == "z_fine":
+                shape = (n_rays, S)
+            else:
+                raise ValueError(f"unknown output {name!r}")
+            res[name] = torch.empty(shape, dtype=torch.float32, device=self.device)
+        res["flags"] = torch.zeros(1, dtype=torch.int32, device=self.device)
+        o = _lib.Outputs()
+        for name in _lib.OUTPUT_FIELDS:
+            setattr(o, name, res[name].data_ptr() if name in res else None)
+        return o, res
+
+    def render(self, c2w, H: int, W: int, *, fx: float, fy: float, cx: float, cy: float, near: float, far: float,
+               rows: Optional[Tuple[int, int]] = None, precision: str = "f16x3",
+               outputs: Sequence[str] = ("rgb", "depth", "acc")) -> Dict[str, torch.Tensor]:
+        """Render rows [rows[0], rows[1]) of each pose.  c2w: [4,4] or [B,4,4] (numpy or CPU tensor)."""
+        poses = np.ascontiguousarray(np.asarray(c2w, dtype=np.float32).reshape(-1, 4, 4))
+        r0, r1 = rows if rows is not None else (0, H)
+        n_rays = poses.shape[0] * (r1 - r0) * W
+        with torch.cuda.device(self.device):
+            o, res = self._alloc(n_rays, outputs)
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+            rc = self._lib.nwe_render(self._ctx, poses.ctypes.data, poses.shape[0], H, W, fx, fy, cx, cy, near, far, r0, r1,
+                                      _lib.PRECISIONS[precision], C.byref(o), stream)
+        self._check(rc, "nwe_render")
+        return res
+
+    def render_rays(self, rays: torch.Tensor, *, precision: str = "f16x3",
+                    outputs: Sequence[str] = ("rgb", "depth", "acc")) -> Dict[str, torch.Tensor]:
+        """rays: [R,11] fp32 on this renderer's device, the layout of nerf/rays/rays.py:26-30."""
+        if rays.dim() != 2 or rays.shape[1] != 11 or rays.dtype != torch.float32:
+            raise ValueError("rays must be float32 [R,11]")
+        rays = rays.to(self.device).contiguous()
+        with torch.cuda.device(self.device):
+            o, res = self._alloc(rays.shape[0], outputs)
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+            rc = self._lib.nwe_render_rays(self._ctx, rays.data_ptr(), rays.shape[0], _lib.PRECISIONS[precision], C.byref(o), stream)
+        self._check(rc, "nwe_render_rays")
+        res["_keepalive_rays"] = rays
+        return res
+
+    def to8b(self, rgb: torch.Tensor) -> torch.Tensor:
+        rgb = rgb.contiguous()
+        out = torch.empty(rgb.shape, dtype=torch.uint8, device=rgb.device)
+        with torch.cuda.device(self.device):
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+            self._check(self._lib.nwe_to8b(self._ctx, rgb.data_ptr(), out.data_ptr(), rgb.numel(), stream), "nwe_to8b")
+        return out
+
+    # -- introspection ----------------------------------------------------------------------------
+    def last_kernel_ms(self) -> float:
+        return float(self._lib.nwe_last_kernel_ms(self._ctx))
+
+    def flops_per_eval(self, which: int) -> int:
+        return int(self._lib.nwe_flops_per_eval(self._ctx, which))
+
+    def packed_stream(self, which: int) -> np.ndarray:
+        n = int(self._lib.nwe_packed_bytes(self._ctx, which))
+        buf = np.empty(n, dtype=np.uint8)
+        if n:
+            rc = self._lib.nwe_packed_copy(self._ctx, which, buf.ctypes.data, n)
+            if rc != _lib.NWE_OK:
+                raise RuntimeError("nwe_packed_copy failed")
+        return buf
+
+    def selftest(self):
+        rep = (C.c_int32 * 8)()
+        rc = self._lib.nwe_selftest(self._ctx, rep)
+        return rc, list(rep)

@@ -1,0 +1,119 @@
+"""numpy emulation of how nwe_kernel_mfma.hip consumes the packed weight stream.
+
+It replays mlp_eval() with the documented lane maps of v_mfma_f32_32x32x16_f16 (A: lane (i,h) holds
+A[i][8h+j]; B: lane (n,h) holds B[8h+j][n]; D: lane (n,h) register r holds D[(r&3)+8(r>>2)+4h][n]) on the
+byte stream the C ABI produced, so the packer's permutations (gamma_col / hidden_col / chunk order /
+bias tile / duplicated head rows) can be checked on the CPU against a plain matmul.  The hardware side
+of the same assumptions is checked on the GPU by nwe_selftest().
+"""
+import numpy as np
+
+TILE = 1024
+LO = 2048.0
+
+
+def split(v):
+    hi = v.astype(np.float16)
+    lo = ((v - hi.astype(np.float32)) * np.float32(LO)).astype(np.float16)
+    return hi, lo
+
+
+class Stream:
+    def __init__(self, buf: np.ndarray):
+        self.buf = buf
+        self.pos = 0
+
+    def tile_f16(self):
+        t = self.buf[self.pos:self.pos + TILE].view(np.float16).reshape(64, 8)   # [lane, j]
+        self.pos += TILE
+        return t
+
+    def bias(self):
+        b = self.buf[self.pos:self.pos + 128].view(np.float32).copy()
+        self.pos += TILE
+        return b
+
+
+def encode(v3, nb, nk):
+    """v3 [3, n] -> (hi, lo) arrays [nk, 2(h), 8(j), n], the kernel's encode<NB, NK>()."""
+    n = v3.shape[1]
+    vals = np.zeros((2, nk * 8, n), dtype=np.float32)
+    for h in range(2):
+        for bl in range(nb):
+            f = np.float32(2.0 ** (bl + nb * h))
+            for c in range(3):
+                arg = (v3[c] * f).astype(np.float32)
+                vals[h, 2 * (bl * 3 + c)] = np.sin(arg.astype(np.float64)).astype(np.float32)
+                vals[h, 2 * (bl * 3 + c) + 1] = np.cos(arg.astype(np.float64)).astype(np.float32)
+        vals[h, 6 * nb] = v3[2] if h else v3[0]
+        vals[h, 6 * nb + 1] = 0 if h else v3[1]
+    hi, lo = split(vals)
+    shp = lambda a: a.reshape(2, nk, 8, n).transpose(1, 0, 2, 3)
+    return shp(hi), shp(lo)
+
+
+def mma_tile(st: Stream, segs, three_pass=True):
+    """One chunk: bias tile + k-steps.  segs = list of (Xhi, Xlo) with shape [ksteps, 2, 8, n].
+    Returns the [32, n] fp32 tile (row-major, i.e. already un-permuted from the D register map)."""
+    bias = st.bias()
+    n = segs[0][0].shape[-1]
+    acc1 = np.repeat(bias[:, None], n, axis=1).astype(np.float64)
+    acc2 = np.zeros((32, n), dtype=np.float64)
+    for xhi, xlo in segs:
+        for s in range(xhi.shape[0]):
+            a_hi = st.tile_f16().astype(np.float64).reshape(2, 32, 8)   # [h, i, j]
+            a_lo = st.tile_f16().astype(np.float64).reshape(2, 32, 8)
+            bh = xhi[s].astype(np.float64)                               # [h, j, n]
+            bl = xlo[s].astype(np.float64)
+            acc1 += np.einsum("hij,hjn->in", a_hi, bh)
+            if three_pass:
+                acc2 += np.einsum("hij,hjn->in", a_lo, bh) + np.einsum("hij,hjn->in", a_hi, bl)
+    return (acc1 + acc2 / LO).astype(np.float32)
+
+
+def tile_to_operand(tile, lower):
+    """[32, n] result tile -> two k-steps of the next B operand, [2, 2(h), 8(j), n] (split_tile())."""
+    v = np.maximum(tile, np.float32(lower))
+    n = v.shape[1]
+    out = np.zeros((2, 2, 8, n), dtype=np.float32)
+    for h in range(2):
+        for r in range(16):
+            out[r >> 3, h, r & 7] = v[(r & 3) + 8 * (r >> 2) + 4 * h]
+    hi, lo = split(out)
+    return hi, lo
+
+
+def layer(st, n_tiles, segs, lower, three_pass=True):
+    his, los = [], []
+    for _ in range(n_tiles):
+        t = mma_tile(st, segs, three_pass)
+        hi, lo = tile_to_operand(t, lower)
+        his.append(hi)
+        los.append(lo)
+    return np.concatenate(his, 0), np.concatenate(los, 0)
+
+
+def mlp_eval(stream_bytes, pts, dirs, D, W, skip, three_pass=True):
+    """pts [n,3] (already divided by 10), dirs [n,3] -> raw [n,4] as the kernel would produce."""
+    st = Stream(stream_bytes)
+    G = encode(pts.T.astype(np.float32), 5, 4)
+    GD = encode(dirs.T.astype(np.float32), 2, 2)
+    NT = W // 32
+    A = layer(st, NT, [G], 0.0, three_pass)
+    npair = D // 2
+    skip_pair = -1 if skip < 0 else skip // 2
+    sigma = None
+    for pair in range(npair):
+        last = pair == npair - 1
+        segs = ([G] if pair == skip_pair else []) + [A]
+        B = layer(st, NT, segs, 0.0, three_pass)
+        A = layer(st, NT, [B], -np.inf if last else 0.0, three_pass)
+        if last:
+            t = mma_tile(st, [B], three_pass)
+            assert np.array_equal(t[0], t[4]), "alpha tile rows 0 and 4 must be copies"
+            sigma = t[0]
+    Bv = layer(st, W // 64, [A, GD], 0.0, three_pass)
+    t = mma_tile(st, [Bv], three_pass)
+    assert np.array_equal(t[0:3], t[4:7]), "rgb tile rows 4..6 must copy rows 0..2"
+    assert st.pos == len(stream_bytes), (st.pos, len(stream_bytes))
+    return np.stack([t[0], t[1], t[2], sigma], axis=1)

@@ -1,0 +1,122 @@
+"""The CPU oracle against the committed golden vectors (made by oracle/make_goldens.py from the
+reference's own functions).  Bit-exact on the torch build the goldens were made with; a different CPU
+kernel selection (another ISA level) may move last bits, so the hard bound asserted is 2e-6."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import nwe_amd
+from oracle import nerf_oracle as O
+
+TOL = 2e-6
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+def _close(a, b, tol=TOL):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape
+    both_nan = np.isnan(a) & np.isnan(b)
+    d = np.abs(np.where(both_nan, 0, a - b))
+    scale = np.maximum(1.0, np.abs(np.where(both_nan, 0, b)))
+    assert np.nanmax(d / scale) <= tol, float(np.nanmax(d / scale))
+    assert not np.isnan(d).any()
+
+
+def test_rays(golden_dir):
+    g = _load(golden_dir, "rays.npz")
+    for (H, W) in [(4, 6), (64, 64)]:
+        fx, fy, cx, cy = O.intrinsics(H, W)
+        for name in ("hor0", "hor30", "tilt"):
+            pose = torch.from_numpy(g[f"pose_{name}"])[None]
+            rays = O.create_rays(pose, H, W, fx, fy, cx, cy, 0.1, 10.0)[0].numpy()
+            _close(rays, g[f"rays_{H}x{W}_{name}"], 1e-7)
+    # ray index is row-major h*W + w, direction is not normalised, +z forward
+    r = g["rays_4x6_hor0"].reshape(4, 6, 11)
+    assert np.all(r[..., 6] == np.float32(0.1)) and np.all(r[..., 7] == np.float32(10.0))
+    np.testing.assert_allclose(np.linalg.norm(r[..., 8:11], axis=-1), 1.0, atol=1e-6)
+
+
+def test_pose_values(golden_dir):
+    # the office_tokyo centre click at hor = 0 / 30 degrees
+    g = _load(golden_dir, "rays.npz")
+    p0 = g["pose_hor0"]
+    np.testing.assert_allclose(p0[:3, :3], [[1, 0, 0], [0, 0, 1], [0, -1, 0]], atol=1e-6)
+    np.testing.assert_allclose(p0[:3, 3], [0, -0.76157, 0.5], atol=1e-5)
+    p30 = g["pose_hor30"]
+    np.testing.assert_allclose(p30[:3, :3], [[0.8660254, 0, 0.5], [-0.5, 0, 0.8660254], [0, -1, 0]], atol=1e-6)
+
+
+def test_embedding(golden_dir):
+    g = _load(golden_dir, "embed.npz")
+    _close(O.embed(torch.from_numpy(g["pts"]), 10, 10).numpy(), g["enc_xyz"])
+    _close(O.embed(torch.from_numpy(g["dirs"]), 4, 1).numpy(), g["enc_dir"])
+    assert g["enc_xyz"].shape[1] == 63 and g["enc_dir"].shape[1] == 27
+
+
+@pytest.mark.parametrize("tag,D,W,seed", [("4x128", 4, 128, 1000), ("8x256", 8, 256, 1001)])
+def test_mlp(golden_dir, tag, D, W, seed):
+    g = _load(golden_dir, "mlp.npz")
+    sd = {k: torch.from_numpy(v) for k, v in nwe_amd.synthetic.make_state_dict(seed, D, W).items()}
+    assert O.net_shape(sd) == (D, W, 63, 27, (4,) if D > 5 else ())
+    y = O.mlp_forward(sd, torch.from_numpy(g[f"x_{tag}"])).numpy()
+    _close(y, g[f"y_{tag}"], 2e-5)
+
+
+def test_raw2outputs(golden_dir):
+    g = _load(golden_dir, "raw2outputs.npz")
+    rgb, disp, acc, w, depth = O.raw2outputs(torch.from_numpy(g["raw"]), torch.from_numpy(g["z"]), torch.from_numpy(g["d"]))
+    for name, v in (("rgb", rgb), ("disp", disp), ("acc", acc), ("weights", w), ("depth", depth)):
+        _close(v.numpy(), g[name])
+    # the documented edge cases of model_utils.py:49-100
+    assert g["acc"][1] == 0 and np.isnan(g["disp"][1])           # sigma <= 0 everywhere -> acc 0 -> disp NaN
+    assert abs(g["acc"][2] - 1) < 1e-6                            # saturated from the first sample
+    assert g["weights"][4, -1] == 0 and g["weights"][5, -1] > 0   # the 1e10 last-interval step
+
+
+def test_sample_pdf(golden_dir):
+    g = _load(golden_dir, "sample_pdf.npz")
+    s = O.sample_pdf(torch.from_numpy(g["bins"]), torch.from_numpy(g["weights"]), 128).numpy()
+    _close(s, g["samples"])
+    assert np.all(np.diff(g["samples"], axis=1) >= -1e-6)         # inverse CDF is monotone
+
+
+def test_tables(golden_dir):
+    g = _load(golden_dir, "tables.npz")
+    for n in (32, 64):
+        assert np.array_equal(torch.linspace(0., 1., steps=n).numpy(), g[f"t_{n}"])
+    assert np.array_equal(torch.linspace(0., 1., steps=128).numpy(), g["u_128"])
+    # torch.linspace is not i/(n-1) bit for bit (SURVEY.md §7 hard part 4): the tables are uploaded, not recomputed
+    naive = (np.arange(64, dtype=np.float32) / np.float32(63))
+    assert (naive != g["t_64"]).sum() > 0
+
+
+def test_end_to_end_c1(golden_dir):
+    g = _load(golden_dir, "e2e_c1.npz")
+    sd = {k: torch.from_numpy(v) for k, v in nwe_amd.synthetic.make_state_dict(1000, 4, 128).items()}
+    fx, fy, cx, cy = O.intrinsics(64, 64)
+    rays = O.create_rays(torch.from_numpy(g["pose"])[None], 64, 64, fx, fy, cx, cy, 0.1, 10.0)[0]
+    out = O.render_rays(rays, sd, None, O.RenderConfig(n_samples=32, n_importance=0))
+    for k in ("rgb_coarse", "depth_coarse", "acc_coarse"):
+        _close(out[k].numpy(), g[k], 5e-5)
+    _close(out["raw_coarse"][:256].numpy(), g["raw_coarse_first256"], 5e-5)
+
+
+def test_end_to_end_c3_subset_small(golden_dir):
+    """64 rays of the 4096-ray C3 golden (the full subset is re-checked on the GPU box against the HIP path)."""
+    g = _load(golden_dir, "e2e_c3_subset.npz")
+    sc = {k: torch.from_numpy(v) for k, v in nwe_amd.synthetic.make_state_dict(1000, 8, 256).items()}
+    sf = {k: torch.from_numpy(v) for k, v in nwe_amd.synthetic.make_state_dict(1001, 8, 256).items()}
+    fx, fy, cx, cy = O.intrinsics(800, 800)
+    idx = torch.from_numpy(g["idx_hor0"][:64])
+    # rays of the subset without building the 640k-ray frame: same arithmetic on the selected pixels
+    full = O.create_rays(torch.from_numpy(g["pose_hor0"])[None], 800, 800, fx, fy, cx, cy, 0.1, 10.0)[0]
+    out = O.render_rays(full[idx].contiguous(), sc, sf, O.RenderConfig())
+    _close(out["raw_fine"].numpy(), g["raw_fine_first64_hor0"], 5e-5)
+    _close(out["z_fine"].numpy(), g["z_fine_first64_hor0"], 1e-6)
+    cliff = np.abs(g["sigma_last_fine_hor0"][:64]) < 1e-5
+    _close(out["rgb_fine"].numpy()[~cliff], g["rgb_fine_hor0"][:64][~cliff], 5e-5)

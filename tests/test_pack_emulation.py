@@ -1,0 +1,36 @@
+"""The MFMA weight stream produced by the C ABI, replayed on the CPU with the documented MFMA lane maps
+(tests/mfma_emulator.py) and compared with the oracle's MLP.  Catches any mismatch between the packer
+(nwe_abi.hip) and the kernel's consumption order without a GPU."""
+import numpy as np
+import pytest
+import torch
+
+import nwe_amd
+from oracle import nerf_oracle as O
+from tests import mfma_emulator as E
+
+
+@pytest.mark.parametrize("D,W,seed,n_tiles", [(8, 256, 1001, 2446), (4, 128, 1000, 376)])
+def test_stream_replay_matches_oracle(D, W, seed, n_tiles):
+    sd = nwe_amd.synthetic.make_state_dict(seed, D, W)
+    r = nwe_amd.Renderer(host_only=True)
+    shape = r.set_network(0, sd)
+    stream = r.packed_stream(0)
+    assert stream.size == n_tiles * 1024
+    g = torch.Generator().manual_seed(3)
+    pts = (torch.rand(32, 3, generator=g) * 2 - 1) * torch.tensor([8.0, 3.0, 1.0])
+    dirs = torch.nn.functional.normalize(torch.randn(32, 3, generator=g), dim=-1)
+    x = torch.cat([O.embed(pts, 10, 10), O.embed(dirs, 4, 1)], -1)
+    ref = O.mlp_forward({k: torch.from_numpy(v) for k, v in sd.items()}, x).numpy()
+    got = E.mlp_eval(stream, (pts / 10).numpy(), dirs.numpy(), D, W, shape[4], three_pass=True)
+    assert np.abs(got - ref).max() < 2e-5, np.abs(got - ref).max()
+    # single-pass fp16 is visibly worse but still close: the split is what buys fp32-grade results
+    got1 = E.mlp_eval(stream, (pts / 10).numpy(), dirs.numpy(), D, W, shape[4], three_pass=False)
+    assert 2e-5 < np.abs(got1 - ref).max() < 5e-2
+
+
+def test_unsupported_shape_has_no_stream():
+    r = nwe_amd.Renderer(host_only=True)
+    r.set_network(0, nwe_amd.synthetic.make_state_dict(5, 6, 64))
+    assert r.packed_stream(0).size == 0      # only the fp32 kernel serves this shape
+    assert r.flops_per_eval(0) == 2 * (63 * 64 + 4 * 64 * 64 + (64 + 63) * 64 + 64 + 64 * 64 + (64 + 27) * 32 + 32 * 3)
