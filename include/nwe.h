@@ -62,6 +62,10 @@ typedef struct nwe_outputs {
     float *raw_coarse;   /* [R,n_samples,4]  network output, [rgb_raw(3), sigma_raw] */
     float *raw_fine;     /* [R,S,4]             */
     float *z_fine;       /* [R,S]  sorted sample depths of the fine pass (handler.py:243) */
+    float *sample_cond;  /* [R]    smallest cdf step (`denom`, nerf/rays/rays.py:113) an importance sample of the ray was
+                                   interpolated in (1.0 if none below 1): the sample depth moves by bin_width/denom per
+                                   unit change of the coarse cdf, so a small value marks a ray whose fine samples are an
+                                   ill-conditioned function of the coarse weights IN THE REFERENCE ALGORITHM ITSELF */
     uint32_t *flags;     /* [1]    NWE_FLAG_* bits, OR-ed (caller zeroes it) */
 } nwe_outputs;
 
@@ -102,6 +106,12 @@ int nwe_render(nwe_ctx *ctx, const float *c2w, int n_poses, int H, int W, float 
                float near, float far, int row_begin, int row_end, int precision, const nwe_outputs *out,
                void *stream);
 
+/* Generate the rays of nwe_render() without rendering them: DEVICE rays_out [n_poses*(row_end-row_begin)*W, 11]
+ * fp32 = [o(3) d(3) near far viewdir(3)], bit-identical to the reference's CPU result.
+ * Replaces: create_rays (nerf/rays/rays.py:6-32). */
+int nwe_create_rays(nwe_ctx *ctx, const float *c2w, int n_poses, int H, int W, float fx, float fy, float cx, float cy,
+                    float near, float far, int row_begin, int row_end, float *rays_out_dev, void *stream);
+
 /* Render precomputed rays: DEVICE [n_rays,11] fp32 = [o(3) d(3) near far viewdir(3)] (rays.py:26-30).
  * Replaces: NeRFReplicaInferenceHandler._render_rays(flat_rays) (handler.py:187-201). */
 int nwe_render_rays(nwe_ctx *ctx, const float *rays_dev, int64_t n_rays, int precision, const nwe_outputs *out,
@@ -124,6 +134,11 @@ float nwe_last_kernel_ms(nwe_ctx *ctx);
  * has no MFMA kernel).  Layout: see DESIGN.md "weight stream".  Works on host-only contexts. */
 int64_t nwe_packed_bytes(const nwe_ctx *ctx, int which);
 int nwe_packed_copy(const nwe_ctx *ctx, int which, void *host_dst, int64_t bytes);
+
+/* Test hook: the NEXT nwe_render_rays call takes the fine-pass sample depths from z_dev (DEVICE [n_rays, S],
+ * sorted per ray) instead of its own importance sampling; cleared after that call.  Lets a test feed the
+ * reference's own depths and compare the fine pass alone. */
+int nwe_debug_set_fine_depths(nwe_ctx *ctx, const float *z_dev);
 
 /* Device self-test of the hardware assumptions the MFMA kernel relies on (fragment layouts of
  * v_mfma_f32_32x32x16_f16, fp16 subnormal operands, LDS-DMA lane order).  report[0..7] receives

@@ -14,12 +14,12 @@ PREC_F16X3, PREC_F16X1, PREC_F32 = 0, 1, 2
 PRECISIONS = {"f16x3": PREC_F16X3, "f16x1": PREC_F16X1, "f32": PREC_F32}
 
 OUTPUT_FIELDS = ("rgb", "depth", "acc", "disp", "z_std", "rgb_coarse", "depth_coarse", "acc_coarse", "disp_coarse",
-                 "raw_coarse", "raw_fine", "z_fine", "flags")
+                 "raw_coarse", "raw_fine", "z_fine", "sample_cond", "flags")
 
 # every symbol include/nwe.h declares (tests/test_abi.py checks the library exports all of them)
 SYMBOLS = ("nwe_create", "nwe_destroy", "nwe_last_error", "nwe_set_network", "nwe_set_sampling", "nwe_render",
-           "nwe_render_rays", "nwe_to8b", "nwe_flops_per_eval", "nwe_last_kernel_ms", "nwe_packed_bytes",
-           "nwe_packed_copy", "nwe_selftest")
+           "nwe_create_rays", "nwe_render_rays", "nwe_to8b", "nwe_flops_per_eval", "nwe_last_kernel_ms", "nwe_packed_bytes",
+           "nwe_packed_copy", "nwe_debug_set_fine_depths", "nwe_selftest")
 
 
 class Outputs(C.Structure):
@@ -49,12 +49,14 @@ def load() -> C.CDLL:
         "nwe_set_network": (I, [P, I, I, I, I, I, I, C.POINTER(P), C.POINTER(P)]),
         "nwe_set_sampling": (I, [P, P, P, I, P, I]),
         "nwe_render": (I, [P, P, I, I, I, F, F, F, F, F, F, I, I, I, C.POINTER(Outputs), P]),
+        "nwe_create_rays": (I, [P, P, I, I, I, F, F, F, F, F, F, I, I, P, P]),
         "nwe_render_rays": (I, [P, P, I64, I, C.POINTER(Outputs), P]),
         "nwe_to8b": (I, [P, P, P, I64, P]),
         "nwe_flops_per_eval": (I64, [P, I]),
         "nwe_last_kernel_ms": (F, [P]),
         "nwe_packed_bytes": (I64, [P, I]),
         "nwe_packed_copy": (I, [P, I, P, I64]),
+        "nwe_debug_set_fine_depths": (I, [P, P]),
         "nwe_selftest": (I, [P, C.POINTER(C.c_int32)]),
     }
     for name, (res, args) in sig.items():

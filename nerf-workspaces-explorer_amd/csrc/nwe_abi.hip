@@ -38,6 +38,7 @@ struct nwe_ctx {
     int poses_cap = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
+    const float* dbg_z_fine = nullptr;
     std::string err;
 };
 
@@ -179,6 +180,25 @@ __global__ void to8b_kernel(const float* __restrict__ x, uint8_t* __restrict__ y
     }
 }
 
+__global__ void create_rays_kernel(RenderArgs a, float* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n_rays) return;
+    const Ray r = load_ray(a, i);
+    float* o = out + i * 11;
+    o[0] = r.ox; o[1] = r.oy; o[2] = r.oz; o[3] = r.dx; o[4] = r.dy; o[5] = r.dz;
+    o[6] = r.near; o[7] = r.far; o[8] = r.vx; o[9] = r.vy; o[10] = r.vz;
+}
+
+int upload_poses(nwe_ctx* c, const float* c2w, int n_poses, hipStream_t stream) {
+    if (n_poses > c->poses_cap) {
+        if (c->d_poses) (void)hipFree(c->d_poses);
+        c->poses_cap = std::max(n_poses, 64);
+        HIPCHK(c, hipMalloc(&c->d_poses, (size_t)c->poses_cap * 16 * sizeof(float)));
+    }
+    HIPCHK(c, hipMemcpyAsync(c->d_poses, c2w, (size_t)n_poses * 16 * sizeof(float), hipMemcpyHostToDevice, stream));
+    return NWE_OK;
+}
+
 int check_ready(nwe_ctx* ctx, const nwe_outputs* out, int precision) {
     if (!ctx || !out) return fail(ctx, NWE_ERR_INVALID, "null context or outputs");
     if (ctx->host_only) return fail(ctx, NWE_ERR_STATE, "host-only context cannot render");
@@ -315,12 +335,8 @@ int nwe_render(nwe_ctx* c, const float* c2w, int n_poses, int H, int W, float fx
         return fail(c, NWE_ERR_INVALID, "bad pose / image / row range");
     if (!(fx != 0.f) || !(fy != 0.f)) return fail(c, NWE_ERR_INVALID, "fx and fy must be non-zero");
     HIPCHK(c, hipSetDevice(c->device));
-    if (n_poses > c->poses_cap) {
-        if (c->d_poses) (void)hipFree(c->d_poses);
-        c->poses_cap = std::max(n_poses, 64);
-        HIPCHK(c, hipMalloc(&c->d_poses, (size_t)c->poses_cap * 16 * sizeof(float)));
-    }
-    HIPCHK(c, hipMemcpyAsync(c->d_poses, c2w, (size_t)n_poses * 16 * sizeof(float), hipMemcpyHostToDevice, (hipStream_t)stream));
+    rc = upload_poses(c, c2w, n_poses, (hipStream_t)stream);
+    if (rc) return rc;
     RenderArgs a = {};
     a.rays = nullptr; a.poses = c->d_poses;
     a.H = H; a.W = W; a.row_begin = row_begin; a.rows = row_end - row_begin;
@@ -330,13 +346,35 @@ int nwe_render(nwe_ctx* c, const float* c2w, int n_poses, int H, int W, float fx
     return launch(c, a, precision, stream);
 }
 
+int nwe_create_rays(nwe_ctx* c, const float* c2w, int n_poses, int H, int W, float fx, float fy, float cx, float cy, float near,
+                    float far, int row_begin, int row_end, float* rays_out_dev, void* stream) {
+    if (!c || c->host_only) return fail(c, NWE_ERR_STATE, "needs a device context");
+    if (!c2w || !rays_out_dev || n_poses < 1 || H < 1 || W < 1 || row_begin < 0 || row_end > H || row_begin > row_end)
+        return fail(c, NWE_ERR_INVALID, "bad pose / image / row range");
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = upload_poses(c, c2w, n_poses, (hipStream_t)stream);
+    if (rc) return rc;
+    RenderArgs a = {};
+    a.poses = c->d_poses;
+    a.H = H; a.W = W; a.row_begin = row_begin; a.rows = row_end - row_begin;
+    a.n_rays = (int64_t)n_poses * a.rows * W;
+    a.fx = fx; a.fy = fy; a.cx = cx; a.cy = cy; a.near = near; a.far = far;
+    if (a.n_rays == 0) return NWE_OK;
+    hipLaunchKernelGGL(create_rays_kernel, dim3((unsigned)((a.n_rays + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, rays_out_dev);
+    HIPCHK(c, hipGetLastError());
+    return NWE_OK;
+}
+
 int nwe_render_rays(nwe_ctx* c, const float* rays_dev, int64_t n_rays, int precision, const nwe_outputs* out, void* stream) {
     int rc = check_ready(c, out, precision);
     if (rc) return rc;
-    if (!rays_dev || n_rays < 0) return fail(c, NWE_ERR_INVALID, "bad rays");
+    if (n_rays < 0 || (!rays_dev && n_rays > 0)) return fail(c, NWE_ERR_INVALID, "bad rays");
+    if (n_rays == 0) { c->dbg_z_fine = nullptr; return NWE_OK; }
     HIPCHK(c, hipSetDevice(c->device));
     RenderArgs a = {};
     a.rays = rays_dev; a.n_rays = n_rays; a.W = 1; a.rows = 1;
+    a.z_fine_in = c->dbg_z_fine;
+    c->dbg_z_fine = nullptr;
     a.out = *out;
     return launch(c, a, precision, stream);
 }
@@ -372,6 +410,12 @@ int nwe_packed_copy(const nwe_ctx* c, int which, void* host_dst, int64_t bytes) 
     if (!c || which < 0 || which > 1 || !host_dst || !c->net[which].set) return NWE_ERR_INVALID;
     if (bytes != (int64_t)c->net[which].stream.size()) return NWE_ERR_INVALID;
     std::memcpy(host_dst, c->net[which].stream.data(), (size_t)bytes);
+    return NWE_OK;
+}
+
+int nwe_debug_set_fine_depths(nwe_ctx* c, const float* z_dev) {
+    if (!c) return NWE_ERR_INVALID;
+    c->dbg_z_fine = z_dev;
     return NWE_OK;
 }
 

@@ -30,6 +30,7 @@ struct RenderArgs {
     const float* t_vals;
     const float* omt_vals;
     const float* u_vals;
+    const float* z_fine_in;  // test hook: fine depths [n_rays, ns+ni] instead of importance sampling
     int n_samples, n_importance;
     nwe_outputs out;
 };
@@ -41,7 +42,7 @@ struct Ray {
 // sqrt(x^2+y^2+z^2) exactly as torch.norm(dim=-1) evaluates a 3-vector on CPU: an FMA chain over the
 // elements in order (measured bit-exact on 20k vectors), correctly rounded sqrt.
 __device__ __forceinline__ float norm3(float x, float y, float z) {
-    return __fsqrt_rn(__fmaf_rn(z, z, __fmaf_rn(y, y, __fmul_rn(x, x))));
+    return __builtin_sqrtf(__fmaf_rn(z, z, __fmaf_rn(y, y, __fmul_rn(x, x))));   // __fsqrt_rn is the NATIVE (1-ulp) sqrt in HIP
 }
 
 // nerf/rays/rays.py:6-71.  idx is the ray index inside the call.
@@ -134,6 +135,7 @@ struct FineSampler {
     int ci, fj, ptr;
     float cur_f;
     double s1, s2;   // sum / sum of squares of the importance samples (z_std, handler.py:267)
+    float min_denom; // smallest cdf step a sample was interpolated in (conditioning diagnostic)
 
     __device__ __forceinline__ float zc(const Ray& r, int i) const { return coarse_z(r, t_tab[i], omt_tab[i]); }
     __device__ __forceinline__ float zmid(const Ray& r, int k) const {       // handler.py:236
@@ -149,7 +151,7 @@ struct FineSampler {
             run += (double)__fdiv_rn(__fadd_rn(wc[i * stride], 1e-5f), sum);
             wc[i * stride] = (float)run;
         }
-        ci = 0; fj = 0; ptr = 0; s1 = 0.0; s2 = 0.0;
+        ci = 0; fj = 0; ptr = 0; s1 = 0.0; s2 = 0.0; min_denom = 1.f;
         cur_f = sample(r, 0);
     }
     // importance sample j (u ascending, so the searchsorted position only moves forward)
@@ -162,6 +164,7 @@ struct FineSampler {
         const float bb = zmid(r, below), ba = zmid(r, above);
         float denom = __fsub_rn(ca, cb);                                     // :113
         if (denom < 1e-5f) denom = 1.f;
+        min_denom = fminf(min_denom, denom);
         const float t = __fdiv_rn(__fsub_rn(u, cb), denom);                  // :118
         const float z = __fadd_rn(bb, __fmul_rn(t, __fsub_rn(ba, bb)));      // :119
         s1 += (double)z; s2 += (double)z * (double)z;

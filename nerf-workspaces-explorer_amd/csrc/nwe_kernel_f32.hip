@@ -117,11 +117,17 @@ __global__ void __launch_bounds__(256) render_f32_kernel(RenderArgs a, NetF32 nc
         if (owner) {
             comp.reset();
             if (pass == 0) { z_cur = coarse_z(ray, s_t[0], s_omt[0]); }
-            else { fs.prepare(ray); z_cur = fs.next(ray); }
+            else {
+                fs.prepare(ray);
+                z_cur = a.z_fine_in ? a.z_fine_in[(live ? ridx : a.n_rays - 1) * S] : fs.next(ray);
+            }
         }
         for (int s = 0; s < S; ++s) {
             if (owner) {
-                if (s + 1 < S) z_next = pass == 0 ? coarse_z(ray, s_t[s + 1], s_omt[s + 1]) : fs.next(ray);
+                if (s + 1 < S) {
+                    if (pass == 0) z_next = coarse_z(ray, s_t[s + 1], s_omt[s + 1]);
+                    else z_next = a.z_fine_in ? a.z_fine_in[(live ? ridx : a.n_rays - 1) * S + s + 1] : fs.next(ray);
+                }
                 float px, py, pz; point_at(ray, z_cur, px, py, pz);
                 s_pt[0 * kRP + tid] = px; s_pt[1 * kRP + tid] = py; s_pt[2 * kRP + tid] = pz;
             }
@@ -168,6 +174,7 @@ __global__ void __launch_bounds__(256) render_f32_kernel(RenderArgs a, NetF32 nc
                 a.out.z_std[ridx] = zs;
                 if (bad(zs)) flags |= NWE_FLAG_ZSTD;
             }
+            if (pass == 1 && a.out.sample_cond) a.out.sample_cond[ridx] = fs.min_denom;
         }
     }
     if (flags && a.out.flags) atomicOr(a.out.flags, flags);

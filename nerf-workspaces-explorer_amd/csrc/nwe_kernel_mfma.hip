@@ -287,7 +287,8 @@ __global__ void __launch_bounds__(256) render_mfma_kernel(RenderArgs a, NetMfma 
 
     const int64_t ridx = ((int64_t)blockIdx.x * kWaves + wave) * kRaysPerWave + (lane & 31);
     const bool live = ridx < a.n_rays && half == 0;
-    const Ray ray = load_ray(a, ridx < a.n_rays ? ridx : a.n_rays - 1);
+    const int64_t rclamp = ridx < a.n_rays ? ridx : a.n_rays - 1;
+    const Ray ray = load_ray(a, rclamp);
 
     Walker<S::CHUNK_BYTES> wk;
     wk.buf0 = smem; wk.parity = 0; wk.wave = wave; wk.lane = lane;
@@ -309,11 +310,17 @@ __global__ void __launch_bounds__(256) render_mfma_kernel(RenderArgs a, NetMfma 
         comp.reset();
         float z_cur, z_next = 0.f;
         if (pass == 0) z_cur = coarse_z(ray, s_t[0], s_omt[0]);
-        else { fs.prepare(ray); z_cur = fs.next(ray); }
+        else {
+            fs.prepare(ray);
+            z_cur = a.z_fine_in ? a.z_fine_in[rclamp * Stot] : fs.next(ray);
+        }
         for (int s = 0; s < Stot; ++s) {
             wk.start(net.stream);
             wk.issue(S::T_L0);   // first chunk of this evaluation flies while gamma(x) is computed
-            if (s + 1 < Stot) z_next = pass == 0 ? coarse_z(ray, s_t[s + 1], s_omt[s + 1]) : fs.next(ray);
+            if (s + 1 < Stot) {
+                if (pass == 0) z_next = coarse_z(ray, s_t[s + 1], s_omt[s + 1]);
+                else z_next = a.z_fine_in ? a.z_fine_in[rclamp * Stot + s + 1] : fs.next(ray);
+            }
             float px, py, pz;
             point_at(ray, z_cur, px, py, pz);
             h8 Ghi[S::KG], Glo[S::KG];
@@ -341,6 +348,7 @@ __global__ void __launch_bounds__(256) render_mfma_kernel(RenderArgs a, NetMfma 
                 a.out.z_std[ridx] = zs;
                 if (bad(zs)) flags |= NWE_FLAG_ZSTD;
             }
+            if (pass == 1 && a.out.sample_cond) a.out.sample_cond[ridx] = fs.min_denom;
         }
     }
     if (flags && a.out.flags) atomicOr(a.out.flags, flags);

@@ -16,7 +16,7 @@ from . import _lib
 LAYER_ORDER_TAIL = ("_views_linears.0", "_feature_linear", "_alpha_linear", "_rgb_linear")
 
 _PER_RAY = {"rgb": 3, "depth": 1, "acc": 1, "disp": 1, "z_std": 1, "rgb_coarse": 3, "depth_coarse": 1,
-            "acc_coarse": 1, "disp_coarse": 1}
+            "acc_coarse": 1, "disp_coarse": 1, "sample_cond": 1}
 
 
 def normalize_state_dict(sd: Mapping[str, object]) -> Dict[str, np.ndarray]:
@@ -149,18 +149,40 @@ class Renderer:
         self._check(rc, "nwe_render")
         return res
 
+    def create_rays(self, c2w, H: int, W: int, *, fx: float, fy: float, cx: float, cy: float, near: float, far: float,
+                    rows: Optional[Tuple[int, int]] = None) -> torch.Tensor:
+        """[B*(rows)*W, 11] device rays, the layout and bits of nerf/rays/rays.py:6-32."""
+        poses = np.ascontiguousarray(np.asarray(c2w, dtype=np.float32).reshape(-1, 4, 4))
+        r0, r1 = rows if rows is not None else (0, H)
+        with torch.cuda.device(self.device):
+            out = torch.empty((poses.shape[0] * (r1 - r0) * W, 11), dtype=torch.float32, device=self.device)
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+            rc = self._lib.nwe_create_rays(self._ctx, poses.ctypes.data, poses.shape[0], H, W, fx, fy, cx, cy, near, far, r0, r1,
+                                           out.data_ptr(), stream)
+        self._check(rc, "nwe_create_rays")
+        return out
+
     def render_rays(self, rays: torch.Tensor, *, precision: str = "f16x3",
-                    outputs: Sequence[str] = ("rgb", "depth", "acc")) -> Dict[str, torch.Tensor]:
-        """rays: [R,11] fp32 on this renderer's device, the layout of nerf/rays/rays.py:26-30."""
+                    outputs: Sequence[str] = ("rgb", "depth", "acc"),
+                    debug_fine_depths: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
+        """rays: [R,11] fp32 on this renderer's device, the layout of nerf/rays/rays.py:26-30.
+        ``debug_fine_depths`` ([R, Ns+Ni], test hook) replaces the importance sampling of the fine pass."""
         if rays.dim() != 2 or rays.shape[1] != 11 or rays.dtype != torch.float32:
             raise ValueError("rays must be float32 [R,11]")
         rays = rays.to(self.device).contiguous()
+        if debug_fine_depths is not None:
+            debug_fine_depths = debug_fine_depths.to(self.device, torch.float32).contiguous()
+            if tuple(debug_fine_depths.shape) != (rays.shape[0], self.n_samples + self.n_importance):
+                raise ValueError("debug_fine_depths must be [R, n_samples + n_importance]")
+            self._lib.nwe_debug_set_fine_depths(self._ctx, debug_fine_depths.data_ptr())
         with torch.cuda.device(self.device):
             o, res = self._alloc(rays.shape[0], outputs)
             stream = torch.cuda.current_stream(self.device).cuda_stream
             rc = self._lib.nwe_render_rays(self._ctx, rays.data_ptr(), rays.shape[0], _lib.PRECISIONS[precision], C.byref(o), stream)
         self._check(rc, "nwe_render_rays")
         res["_keepalive_rays"] = rays
+        if debug_fine_depths is not None:
+            res["_keepalive_depths"] = debug_fine_depths
         return res
 
     def to8b(self, rgb: torch.Tensor) -> torch.Tensor:

@@ -94,6 +94,22 @@ def ref_volumetric_rendering(ray_batch, net_c, net_f, n_samples, n_importance, n
     return out
 
 
+def ref_min_denom(w_coarse, n_importance):
+    """Per ray: the smallest cdf step (`denom`, nerf/rays/rays.py:113) an importance sample is interpolated in, with
+    the reference's own ops (rays.py:87-117).  Steps below 1e-5 are replaced by 1 there (:114), as here."""
+    weights = w_coarse[..., 1:-1] + 1e-5
+    pdf = weights / torch.sum(weights, -1, keepdim=True)
+    cdf = torch.cumsum(pdf, -1)
+    cdf = torch.cat([torch.zeros_like(cdf[..., :1]), cdf], -1)
+    u = torch.linspace(0., 1., steps=n_importance).expand(list(cdf.shape[:-1]) + [n_importance]).contiguous()
+    inds = torch.searchsorted(cdf, u, right=True)
+    below = torch.max(torch.zeros_like(inds - 1), inds - 1)
+    above = torch.min((cdf.shape[-1] - 1) * torch.ones_like(inds), inds)
+    denom = torch.gather(cdf, 1, above) - torch.gather(cdf, 1, below)
+    denom = torch.where(denom < 1e-5, torch.ones_like(denom), denom)
+    return denom.min(dim=-1).values
+
+
 def np_dict(d):
     return {k: (v.numpy() if isinstance(v, torch.Tensor) else np.asarray(v)) for k, v in d.items()}
 
@@ -223,6 +239,7 @@ def main() -> None:
         e2e[f"pose_{name}"] = POSES[name][0].numpy()
         for k in ("rgb_fine", "depth_fine", "acc_fine", "disp_fine", "z_std", "rgb_coarse", "depth_coarse", "acc_coarse"):
             e2e[f"{k}_{name}"] = ref[k].numpy()
+        e2e[f"min_denom_{name}"] = ref_min_denom(ref["weights_coarse"], 128).numpy()
         e2e[f"sigma_last_fine_{name}"] = ref["raw_fine"][:, -1, 3].numpy()
         e2e[f"sigma_last_coarse_{name}"] = ref["raw_coarse"][:, -1, 3].numpy()
         e2e[f"raw_fine_first64_{name}"] = ref["raw_fine"][:64].numpy()
@@ -232,6 +249,26 @@ def main() -> None:
               f"acc {ref['acc_fine'].min():.3f}..{ref['acc_fine'].max():.3f}; depth {ref['depth_fine'].min():.2f}.."
               f"{ref['depth_fine'].max():.2f}")
     np.savez_compressed(os.path.join(GOLD, "e2e_c3_subset.npz"), **e2e)
+
+    # (9) same geometry, thin-fog coarse network: importance sampling well conditioned on every ray ---------
+    print("[9] end-to-end C3 subset, thin-fog coarse network")
+    sd_fog = synthetic.thin_fog(sd_c)
+    net_fog = load_ref_model(8, 256, sd_fog)
+    full = ref_create_rays(1, POSES["hor30"], 800, 800, fx, fy, cx, cy, 0.1, 10.0, True)[0]
+    idx = (torch.arange(2048) * 311 + 5) % (800 * 800)
+    rays = full[idx].contiguous()
+    ref = ref_volumetric_rendering(rays, net_fog, net_f, 64, 128, 1024 * 32)
+    mine = O.render_rays(rays, {k: torch.from_numpy(v) for k, v in sd_fog.items()}, tf, O.RenderConfig())
+    for k in ref:
+        same(mine[k], ref[k], f"fog {k}")
+    md = ref_min_denom(ref["weights_coarse"], 128)
+    print(f"    fog: smallest cdf step over all rays {md.min():.2e}; acc_coarse {ref['acc_coarse'].min():.3f}..{ref['acc_coarse'].max():.3f}; "
+          f"rgb_fine {ref['rgb_fine'].min():.3f}..{ref['rgb_fine'].max():.3f}")
+    fog = {"idx": idx.numpy(), "pose": POSES["hor30"][0].numpy(), "min_denom": md.numpy(),
+           "sigma_last_fine": ref["raw_fine"][:, -1, 3].numpy(), "z_fine_first128": ref["z_fine"][:128].numpy()}
+    for k in ("rgb_fine", "depth_fine", "acc_fine", "disp_fine", "z_std", "rgb_coarse", "depth_coarse", "acc_coarse"):
+        fog[k] = ref[k].numpy()
+    np.savez_compressed(os.path.join(GOLD, "e2e_fog.npz"), **fog)
     print("goldens written to", GOLD)
 
 

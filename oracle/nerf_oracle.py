@@ -84,6 +84,21 @@ def sample_pdf(bins: torch.Tensor, weights: torch.Tensor, n_samples: int) -> tor
     return bin_lo + t * (bin_hi - bin_lo)                           # rays.py:119
 
 
+def sample_pdf_terms(weights: torch.Tensor, n_samples: int):
+    """The intermediates of sample_pdf (rays.py:87-118) for conditioning analysis: (cdf_lo, cdf_hi, denom, below,
+    above) per importance sample, with `denom` AFTER the < 1e-5 -> 1 replacement (:114)."""
+    weights = weights + 1e-5
+    pdf = weights / torch.sum(weights, -1, keepdim=True)
+    cdf = torch.cat([torch.zeros_like(pdf[..., :1]), torch.cumsum(pdf, -1)], -1)
+    u = torch.linspace(0., 1., steps=n_samples).expand(list(cdf.shape[:-1]) + [n_samples]).contiguous()
+    inds = torch.searchsorted(cdf, u, right=True)
+    below, above = torch.clamp(inds - 1, min=0), torch.clamp(inds, max=cdf.shape[-1] - 1)
+    cdf_lo, cdf_hi = torch.gather(cdf, 1, below), torch.gather(cdf, 1, above)
+    denom = cdf_hi - cdf_lo
+    denom = torch.where(denom < 1e-5, torch.ones_like(denom), denom)
+    return cdf_lo, cdf_hi, denom, below, above
+
+
 # --------------------------------------------------------------------------
 # positional encoding  (nerf/models/embedding.py)
 # --------------------------------------------------------------------------
@@ -227,6 +242,19 @@ def volumetric_rendering(ray_batch: torch.Tensor, coarse: Dict[str, torch.Tensor
                     "z_std": torch.std(z_samples, dim=-1, unbiased=False),                # :267
                     "raw_fine": raw_f, "z_fine": z_all, "z_samples": z_samples})
     return out
+
+
+def fine_pass_given_depths(ray_batch: torch.Tensor, z_all: torch.Tensor, fine: Dict[str, torch.Tensor],
+                           cfg: RenderConfig) -> Dict[str, torch.Tensor]:
+    """The fine half of handler.py:246-254 on caller-provided sorted depths z_all [N, Ns+Ni]: points, fine network,
+    compositing.  Used to compare the fine pass alone (the importance depths are an ill-conditioned function of the
+    coarse weights, DESIGN.md "reference instabilities")."""
+    rays_o, rays_d, viewdirs = ray_batch[:, 0:3], ray_batch[:, 3:6], ray_batch[:, -3:]
+    pts = rays_o[..., None, :] + rays_d[..., None, :] * z_all[..., :, None]
+    with torch.no_grad():
+        raw = run_network(pts, viewdirs, fine, cfg.freqs_xyz, cfg.freqs_dir, cfg.net_chunk)
+        rgb, disp, acc, w, depth = raw2outputs(raw, z_all, rays_d, cfg.white_bkgd)
+    return {"rgb_fine": rgb, "disp_fine": disp, "acc_fine": acc, "depth_fine": depth, "raw_fine": raw}
 
 
 def render_rays(flat_rays: torch.Tensor, coarse, fine, cfg: RenderConfig,

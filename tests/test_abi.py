@@ -1,0 +1,84 @@
+"""The C-ABI shared library: loads, exports every symbol include/nwe.h declares, and its host-only paths
+(context, validation, packing) behave; no device work here."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import nwe_amd
+from nwe_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "nwe.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(nwe_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    names = declared_symbols()
+    assert "nwe_render" in names and "nwe_set_network" in names and len(names) >= 14
+    lib = C.CDLL(_lib.LIB_PATH)
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/nwe.h but not exported"
+    assert sorted(_lib.SYMBOLS) == names        # the ctypes binding covers exactly the header
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "libnwe_hip.so"))
+    with pytest.raises(RuntimeError, match="is missing"):
+        nwe_amd.Renderer(host_only=True)
+
+
+def test_host_only_context_validation():
+    r = nwe_amd.Renderer(host_only=True)
+    sd = nwe_amd.synthetic.make_state_dict(1, 4, 128)
+    assert r.set_network(0, sd) == (4, 128, 63, 27, -1)
+    # checkpoint spelling without the leading underscore (handler.py:150-164) is accepted
+    assert r.set_network(1, {k[1:]: v for k, v in sd.items()}) == (4, 128, 63, 27, -1)
+    bad = dict(sd)
+    bad["_rgb_linear.weight"] = np.zeros((3, 65), np.float32)
+    with pytest.raises(ValueError, match="_rgb_linear"):
+        r.set_network(0, bad)
+    with pytest.raises(NotImplementedError):
+        r.set_network(0, nwe_amd.synthetic.make_state_dict(1, 4, 512))      # width > 256
+    r.set_sampling(64, 128)
+    with pytest.raises(NotImplementedError):
+        r.set_sampling(300, 0)
+    # a host-only context refuses to render instead of falling back to anything
+    lib = _lib.load()
+    out = _lib.Outputs()
+    rc = lib.nwe_render_rays(r._ctx, None, 0, 0, C.byref(out), None)
+    assert rc == _lib.NWE_ERR_STATE and b"host-only" in lib.nwe_last_error(r._ctx)
+    r.close()
+
+
+def test_flops_per_eval_match_baseline():
+    r = nwe_amd.Renderer(host_only=True)
+    r.set_network(0, nwe_amd.synthetic.make_state_dict(1, 8, 256))
+    r.set_network(1, nwe_amd.synthetic.make_state_dict(1, 4, 128))
+    assert r.flops_per_eval(0) == 1186816 and r.flops_per_eval(1) == 167680
+
+
+def test_stream_layout_properties():
+    """Weight stream invariants the kernel relies on: tile-aligned, bias tile first, hi + lo*2^-11 == weight."""
+    sd = nwe_amd.synthetic.make_state_dict(9, 4, 128)
+    r = nwe_amd.Renderer(host_only=True)
+    r.set_network(0, sd)
+    s = r.packed_stream(0)
+    assert s.size % 1024 == 0
+    bias0 = s[:128].view(np.float32)
+    assert np.array_equal(bias0, sd["_pts_linears.0.bias"][:32]) and not s[128:1024].any()
+    hi = s[1024:2048].view(np.float16).astype(np.float64)
+    lo = s[2048:3072].view(np.float16).astype(np.float64)
+    # lane 0 (row 0, half 0), element 0 of k-step 0 is gamma slot 0 = sin(2^0 x) = column 3 of the encoding
+    w = sd["_pts_linears.0.weight"]
+    assert abs(hi[0] + lo[0] / 2048 - w[0, 3]) < 1e-7 * max(1, abs(w[0, 3]))
+    assert abs(hi[1] + lo[1] / 2048 - w[0, 6]) < 1e-7                       # slot 1 = cos(2^0 x) = column 6
+    rec = hi + lo / 2048
+    assert np.abs(rec).max() <= np.abs(w).max() * 1.0001

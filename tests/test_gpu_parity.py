@@ -63,6 +63,23 @@ def test_selftest_hardware_assumptions(r_c1):
     assert rep[5] < 500, f"expf relative error {rep[5]}e-9"
 
 
+def test_create_rays_bit_exact(r_c1, golden_dir):
+    """nwe_create_rays against the reference's create_rays output (nerf/rays/rays.py:6-32), every bit."""
+    g = np.load(os.path.join(golden_dir, "rays.npz"))
+    for (H, W) in [(4, 6), (64, 64)]:
+        fx, fy, cx, cy = O.intrinsics(H, W)
+        for name in ("hor0", "hor30", "tilt"):
+            got = r_c1.create_rays(g[f"pose_{name}"], H, W, fx=fx, fy=fy, cx=cx, cy=cy, near=0.1, far=10.0).cpu().numpy()
+            gold = g[f"rays_{H}x{W}_{name}"]
+            bad_cols = [c for c in range(11) if not np.array_equal(got[:, c], gold[:, c])]
+            assert not bad_cols, (H, W, name, bad_cols, np.abs(got - gold).max(0))
+    fx, fy, cx, cy = O.intrinsics(800, 800)
+    for name in ("hor0", "hor30"):
+        got = r_c1.create_rays(g[f"pose_{name}"], 800, 800, fx=fx, fy=fy, cx=cx, cy=cy, near=0.1, far=10.0)
+        got = got.reshape(800, 800, 11)[::37, ::37].cpu().numpy()
+        assert np.array_equal(got, g[f"rays_800_stride37_{name}"]), name
+
+
 def test_ray_generation_is_bit_exact(r_c1, golden_dir):
     """nwe_render (in-kernel rays from the pose) == nwe_render_rays on the reference's own rays, bit for bit,
     in the fp32 mode: only possible if origins, directions and view dirs are generated bit-exactly."""
@@ -116,40 +133,114 @@ def test_c1_frame_against_golden(r_c1, golden_dir, precision):
 @pytest.mark.parametrize("precision", ["f32", "f16x3"])
 @pytest.mark.parametrize("pose", ["hor0", "hor30"])
 def test_c3_subset_against_golden(r_c3, golden_dir, precision, pose):
-    """BASELINE config 3 (800x800, 64+128, 8x256) on the committed strided 4096-ray subset."""
+    """BASELINE config 3 (800x800, 64+128, 8x256, raw random networks) on the committed strided 4096-ray subset.
+
+    With unrelated random coarse/fine networks the reference's importance sampling is ill conditioned on part of
+    the rays (an importance sample in a nearly empty coarse bin moves by up to ~1e-2 for a 1e-6 relative change of
+    the coarse weights, and the `denom < 1e-5` switch of nerf/rays/rays.py:114 is a discontinuity): perturbing the
+    reference's OWN coarse network output by 1e-6 relative moves ~1 % of its fine pixels by more than 1e-4
+    (tools/reference_instability.py).  So the comparison is staged:
+      T1  coarse pass, every ray, full tolerance;
+      T2  sample depths: nearly all equal, none further than a fraction of a coarse bin;
+      T3  fine pass ALONE, every ray, full tolerance: the oracle's fine pass evaluated on the kernel's depths,
+          and the kernel's fine pass evaluated on the reference's depths (debug hook);
+      T4  end to end: PSNR, median, and the share of rays above 1e-4 bounded.
+    """
     g = np.load(os.path.join(golden_dir, "e2e_c3_subset.npz"))
     fx, fy, cx, cy = O.intrinsics(800, 800)
     full = O.create_rays(torch.from_numpy(g[f"pose_{pose}"])[None], 800, 800, fx, fy, cx, cy, 0.1, 10.0)[0]
-    rays = full[torch.from_numpy(g[f"idx_{pose}"])].contiguous().cuda()
+    rays_cpu = full[torch.from_numpy(g[f"idx_{pose}"])].contiguous()
+    rays = rays_cpu.cuda()
     out = r_c3.render_rays(rays, precision=precision,
                            outputs=("rgb", "depth", "acc", "disp", "z_std", "rgb_coarse", "depth_coarse", "acc_coarse",
-                                    "raw_fine", "z_fine"))
-    z = out["z_fine"].cpu().numpy()
-    print(precision, pose, "z_fine max err", np.abs(z[:64] - g[f"z_fine_first64_{pose}"]).max())
-    assert np.abs(z[:64] - g[f"z_fine_first64_{pose}"]).max() < 2e-4     # sorted merge == torch.sort(cat(...))
-    assert np.all(np.diff(z, axis=1) >= -1e-6)
-    raw = out["raw_fine"].cpu().numpy()
-    print(precision, pose, "raw_fine max err", np.abs(raw[:64] - g[f"raw_fine_first64_{pose}"]).max())
-    cliff = (np.abs(g[f"sigma_last_fine_{pose}"]) < 1e-5)
-    cliff_c = (np.abs(g[f"sigma_last_coarse_{pose}"]) < 1e-5)
-    rgb = out["rgb"].cpu().numpy()
-    err = np.abs(rgb - g[f"rgb_fine_{pose}"])
-    print(precision, pose, "rgb_fine max err", err[~cliff].max(), "cliff rays", int(cliff.sum()), "cliff max", err[cliff].max() if cliff.any() else 0,
-          "psnr", psnr(rgb, g[f"rgb_fine_{pose}"]))
-    assert err[~cliff].max() <= RGB_TOL
-    assert psnr(rgb, g[f"rgb_fine_{pose}"]) > 50
-    assert np.abs(out["depth"].cpu().numpy() - g[f"depth_fine_{pose}"])[~cliff].max() / FAR <= 1e-4
-    assert np.abs(out["acc"].cpu().numpy() - g[f"acc_fine_{pose}"])[~cliff].max() <= 1e-4
-    assert np.abs(out["z_std"].cpu().numpy() - g[f"z_std_{pose}"]).max() <= 1e-4
+                                    "z_fine", "sample_cond"))
+    tag = f"[{precision} {pose}]"
+    # T1 ------------------------------------------------------------------------------------------
+    cliff_c = np.abs(g[f"sigma_last_coarse_{pose}"]) < 1e-5
     errc = np.abs(out["rgb_coarse"].cpu().numpy() - g[f"rgb_coarse_{pose}"])
+    print(tag, "T1 coarse rgb max err", errc[~cliff_c].max(), "cliff rays", int(cliff_c.sum()))
     assert errc[~cliff_c].max() <= RGB_TOL
-    assert cliff.sum() <= 8 and cliff_c.sum() <= 8       # a handful per 4096 rays at most, explained above
+    assert np.abs(out["depth_coarse"].cpu().numpy() - g[f"depth_coarse_{pose}"])[~cliff_c].max() / FAR <= 1e-4
+    assert np.abs(out["acc_coarse"].cpu().numpy() - g[f"acc_coarse_{pose}"])[~cliff_c].max() <= 1e-4
+    # T2 ------------------------------------------------------------------------------------------
+    z = out["z_fine"].cpu()
+    zerr = np.abs(z[:64].numpy() - g[f"z_fine_first64_{pose}"])
+    print(tag, "T2 depths: max err", zerr.max(), "share > 2e-5:", (zerr > 2e-5).mean())
+    assert (zerr > 2e-5).mean() < 0.02 and zerr.max() < 0.16
+    assert np.all(np.diff(z.numpy(), axis=1) >= -1e-6)                      # merge output is sorted
+    cond = out["sample_cond"].cpu().numpy()
+    assert np.median(np.abs(np.log(cond / g[f"min_denom_{pose}"]))) < 1e-3  # diagnostic agrees with the reference's denom
+    # T3 ------------------------------------------------------------------------------------------
+    sf = _t(_sd(1001, 8, 256))
+    fo = O.fine_pass_given_depths(rays_cpu, z, sf, O.RenderConfig())
+    cliff = fo["raw_fine"][:, -1, 3].abs().numpy() < 1e-5
+    e3 = np.abs(out["rgb"].cpu().numpy() - fo["rgb_fine"].numpy())
+    print(tag, "T3 fine pass on the kernel's depths: rgb max err", e3[~cliff].max(), "depth", np.abs(out["depth"].cpu().numpy() - fo["depth_fine"].numpy())[~cliff].max(),
+          "cliff rays", int(cliff.sum()))
+    assert e3[~cliff].max() <= RGB_TOL
+    assert np.abs(out["depth"].cpu().numpy() - fo["depth_fine"].numpy())[~cliff].max() / FAR <= 1e-4
+    assert np.abs(out["acc"].cpu().numpy() - fo["acc_fine"].numpy())[~cliff].max() <= 1e-4
+    hook = r_c3.render_rays(rays[:64].contiguous(), precision=precision, outputs=("rgb", "depth", "raw_fine"),
+                            debug_fine_depths=torch.from_numpy(g[f"z_fine_first64_{pose}"]))
+    cl64 = np.abs(g[f"sigma_last_fine_{pose}"][:64]) < 1e-5
+    eh = np.abs(hook["rgb"].cpu().numpy() - g[f"rgb_fine_{pose}"][:64])
+    print(tag, "T3 kernel fine pass on the reference's depths: rgb max err", eh[~cl64].max(), "raw",
+          np.abs(hook["raw_fine"].cpu().numpy() - g[f"raw_fine_first64_{pose}"]).max())
+    assert eh[~cl64].max() <= RGB_TOL
+    assert np.abs(hook["raw_fine"].cpu().numpy() - g[f"raw_fine_first64_{pose}"]).max() < 5e-5
+    # T4 ------------------------------------------------------------------------------------------
+    cliff_g = np.abs(g[f"sigma_last_fine_{pose}"]) < 1e-5
+    rgb = out["rgb"].cpu().numpy()
+    err = np.abs(rgb - g[f"rgb_fine_{pose}"]).max(-1)
+    print(tag, "T4 end to end: psnr", psnr(rgb, g[f"rgb_fine_{pose}"]), "median", np.median(err), "share > 1e-4:",
+          (err > RGB_TOL).mean(), "max", err.max(), "cliff rays", int(cliff_g.sum()))
+    assert psnr(rgb, g[f"rgb_fine_{pose}"]) > 50
+    assert np.median(err) < 2e-6 and (err > RGB_TOL).mean() < 0.03 and err.max() < 2e-2
+    assert cliff_g.sum() <= 8 and cliff_c.sum() <= 8
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+def test_fog_scene_every_ray_within_tolerance(golden_dir, precision):
+    """Same geometry and fine network, thin-fog coarse network (synthetic.thin_fog): every coarse bin carries
+    weight, the importance sampling is well conditioned, and the END-TO-END result must match the reference on
+    EVERY ray: rgb 1e-4, depth/far 1e-4, acc 1e-4, z_std 1e-4, sample depths 2e-5."""
+    g = np.load(os.path.join(golden_dir, "e2e_fog.npz"))
+    r = nwe_amd.Renderer(0)
+    r.set_network(0, nwe_amd.synthetic.thin_fog(_sd(1000, 8, 256)))
+    r.set_network(1, _sd(1001, 8, 256))
+    r.set_sampling(64, 128)
+    fx, fy, cx, cy = O.intrinsics(800, 800)
+    full = O.create_rays(torch.from_numpy(g["pose"])[None], 800, 800, fx, fy, cx, cy, 0.1, 10.0)[0]
+    rays = full[torch.from_numpy(g["idx"])].contiguous().cuda()
+    out = r.render_rays(rays, precision=precision, outputs=("rgb", "depth", "acc", "disp", "z_std", "rgb_coarse", "depth_coarse",
+                                                             "acc_coarse", "z_fine", "sample_cond"))
+    cliff = np.abs(g["sigma_last_fine"]) < 1e-5
+    err = np.abs(out["rgb"].cpu().numpy() - g["rgb_fine"])
+    zerr = np.abs(out["z_fine"][:128].cpu().numpy() - g["z_fine_first128"])
+    print(f"[{precision} fog] rgb max err", err[~cliff].max(), "depth", np.abs(out["depth"].cpu().numpy() - g["depth_fine"])[~cliff].max(),
+          "z_std", np.abs(out["z_std"].cpu().numpy() - g["z_std"]).max(), "z_fine", zerr.max(), "cliff rays", int(cliff.sum()),
+          "psnr", psnr(out["rgb"].cpu().numpy(), g["rgb_fine"]))
+    assert err[~cliff].max() <= RGB_TOL
+    assert np.abs(out["depth"].cpu().numpy() - g["depth_fine"])[~cliff].max() / FAR <= 1e-4
+    assert np.abs(out["acc"].cpu().numpy() - g["acc_fine"])[~cliff].max() <= 1e-4
+    assert np.abs(out["z_std"].cpu().numpy() - g["z_std"]).max() <= 1e-4
+    assert zerr.max() <= 2e-5
+    assert np.abs(out["rgb_coarse"].cpu().numpy() - g["rgb_coarse"]).max() <= RGB_TOL
+    ratio = out["sample_cond"].cpu().numpy() / g["min_denom"]              # the min over samples may pick a neighbouring bin
+    assert np.median(np.abs(ratio - 1)) < 1e-4 and np.abs(ratio - 1).max() < 0.2
+    d, dref = out["disp"].cpu().numpy(), g["disp_fine"]
+    assert np.array_equal(np.isnan(d)[~cliff], np.isnan(dref)[~cliff])     # acc == 0 -> NaN, as torch.max propagates it
+    # disparity = 1/(depth/acc) is a ratio of two sums: compared (relative 1e-3) where acc is not tiny
+    ok = ~cliff & ~np.isnan(dref) & (g["acc_fine"] > 1e-2)
+    assert (np.abs(d - dref)[ok] / np.abs(dref[ok])).max() <= 1e-3
+    assert cliff.sum() <= 4
+    r.close()
 
 
 def test_generic_shape_fp32_against_live_oracle():
     """A shape with no MFMA instantiation (6x64, skip after layer 2, 48+40 samples) through the fp32 kernel,
     checked against the oracle run live on the same rays; the MFMA modes must refuse it loudly."""
-    sd_c = nwe_amd.synthetic.make_state_dict(11, 6, 64, skips=(2,))
+    sd_c = nwe_amd.synthetic.thin_fog(nwe_amd.synthetic.make_state_dict(11, 6, 64, skips=(2,)))   # well-conditioned sampling
     sd_f = nwe_amd.synthetic.make_state_dict(12, 6, 64, skips=(2,))
     r = nwe_amd.Renderer(0)
     assert r.set_network(0, sd_c) == (6, 64, 63, 27, 2)
@@ -198,28 +289,44 @@ def test_chunking_and_batching_are_result_neutral(r_c3):
     assert torch.equal(both["rgb"], torch.cat([whole["rgb"], other["rgb"]]))
 
 
-def test_mfma_against_fp32_kernel_full_frame(r_c3):
-    """400x400x(64+128) (BASELINE config 2 geometry with the fine pass): the MFMA path against the on-device
-    fp32 FMA path on all 160 000 rays -- far more rays than the CPU oracle can cover in a test."""
-    fx, fy, cx, cy = O.intrinsics(400, 400)
+def test_c3_full_frame_mfma_against_fp32_kernel():
+    """BASELINE config 3 at FULL size (800x800, 64+128, 8x256; 640 000 rays, 1.6e8 MLP evaluations): the MFMA path
+    against the on-device fp32 FMA path on every ray -- 150x more rays than the CPU oracle can cover in a test.
+    Thin-fog coarse network so that every ray is comparable at full tolerance (see the subset test)."""
+    r = nwe_amd.Renderer(0)
+    r.set_network(0, nwe_amd.synthetic.thin_fog(_sd(1000, 8, 256)))
+    r.set_network(1, _sd(1001, 8, 256))
+    r.set_sampling(64, 128)
+    fx, fy, cx, cy = O.intrinsics(800, 800)
     pose = O.camera_pose((0.0, -0.5, -0.75 / np.cos(-10 / 180 * np.pi), 0.0, -90.0, 0.0), (0, 0, 0, -30.0, 0.0, 0.0))[0].numpy()
     kw = dict(fx=fx, fy=fy, cx=cx, cy=cy, near=0.1, far=10.0)
-    ref = r_c3.render(pose, 400, 400, precision="f32", outputs=("rgb", "depth", "acc", "raw_fine"), **kw)
+    ref = r.render(pose, 800, 800, precision="f32", outputs=("rgb", "depth", "acc", "raw_fine"), **kw)
+    ms32 = r.last_kernel_ms()
     sig_last = ref["raw_fine"][:, -1, 3].abs().cpu().numpy()
     del ref["raw_fine"]
-    got = r_c3.render(pose, 400, 400, precision="f16x3", outputs=("rgb", "depth", "acc"), **kw)
+    torch.cuda.empty_cache()
+    got = r.render(pose, 800, 800, precision="f16x3", outputs=("rgb", "depth", "acc"), **kw)
+    ms = r.last_kernel_ms()
     cliff = sig_last < 1e-5
     err = (got["rgb"] - ref["rgb"]).abs().cpu().numpy()
-    print("400x400 mfma vs fp32: rgb max err", err[~cliff].max(), "cliff rays", int(cliff.sum()), "psnr",
-          psnr(got["rgb"].cpu().numpy(), ref["rgb"].cpu().numpy()), "kernel ms", r_c3.last_kernel_ms())
+    print("800x800 mfma vs fp32: rgb max err", err[~cliff].max(), "cliff rays", int(cliff.sum()), "psnr",
+          psnr(got["rgb"].cpu().numpy(), ref["rgb"].cpu().numpy()), "kernel ms mfma", ms, "fp32", ms32)
     assert err[~cliff].max() <= RGB_TOL
     assert psnr(got["rgb"].cpu().numpy(), ref["rgb"].cpu().numpy()) > 50
     assert ((got["depth"] - ref["depth"]).abs().cpu().numpy()[~cliff].max()) / FAR <= 1e-4
-    assert cliff.sum() <= 40
-    fast = r_c3.render(pose, 400, 400, precision="f16x1", outputs=("rgb",), **kw)
-    p = psnr(fast["rgb"].cpu().numpy(), ref["rgb"].cpu().numpy())
-    print("400x400 single-pass fp16 vs fp32: psnr", p, "max err", (fast["rgb"] - ref["rgb"]).abs().max().item())
-    assert p > 50
+    assert ((got["acc"] - ref["acc"]).abs().cpu().numpy()[~cliff].max()) <= 1e-4
+    assert cliff.sum() <= 64
+    assert int(got["flags"].item()) & 0x7 == 0
+    fast = r.render(pose, 800, 800, precision="f16x1", outputs=("rgb",), **kw)
+    # single-pass fp16 is the fast preview mode (raw sigma error ~1e-3): the last-interval step then flips on rays
+    # whose last raw sigma is within a few 1e-3 of zero, so its PSNR is quoted with and without those rays
+    wide = sig_last < 5e-3
+    p_all = psnr(fast["rgb"].cpu().numpy(), ref["rgb"].cpu().numpy())
+    p = psnr(fast["rgb"].cpu().numpy()[~wide], ref["rgb"].cpu().numpy()[~wide])
+    print("800x800 single-pass fp16 vs fp32: psnr", p, "(all rays:", p_all, ") rays within 5e-3 of the step:", int(wide.sum()),
+          "max err", (fast["rgb"] - ref["rgb"]).abs().cpu().numpy()[~wide].max(), "kernel ms", r.last_kernel_ms())
+    assert p > 50 and p_all > 40
+    r.close()
 
 
 def test_to8b_truncates(r_c1):
@@ -233,7 +340,8 @@ def test_handler_drop_in_surface():
     h = nwe_amd.NeRFReplicaInferenceHandler("office_tokyo", "/nonexistent/model.ckpt")
     with pytest.raises(RuntimeError, match="cannot be found"):
         h.initialize_models()
-    h.initialize_models(state_dicts=(_sd(1000, 8, 256), _sd(1001, 8, 256)))
+    sd_c = nwe_amd.synthetic.thin_fog(_sd(1000, 8, 256))
+    h.initialize_models(state_dicts=(sd_c, _sd(1001, 8, 256)))
     init = nwe_amd.COORD(x=0.0, y=-0.5, z=-0.76, yaw=0.0, pitch=-90.0, roll=0.0)
     img = h.render_coordinates(init, nwe_amd.COORD(yaw=-30.0))
     assert img.dtype == np.uint8 and img.shape == (240, 320, 3) and img.flags["C_CONTIGUOUS"]
@@ -246,7 +354,7 @@ def test_handler_drop_in_surface():
     fx, fy, cx, cy = O.intrinsics(240, 320)
     rays = O.create_rays(torch.from_numpy(pose)[None], 240, 320, fx, fy, cx, cy, 0.1, 10.0)[0]
     idx = torch.arange(0, 240 * 320, 601)
-    ref = O.render_rays(rays[idx].contiguous(), _t(_sd(1000, 8, 256)), _t(_sd(1001, 8, 256)), O.RenderConfig())
+    ref = O.render_rays(rays[idx].contiguous(), _t(sd_c), _t(_sd(1001, 8, 256)), O.RenderConfig())
     cliff = ref["raw_fine"][:, -1, 3].abs().numpy() < 1e-5
     got = out["rgb"].reshape(-1, 3)[idx.cuda()].cpu().numpy()
     assert np.abs(got - ref["rgb_fine"].numpy())[~cliff].max() <= RGB_TOL

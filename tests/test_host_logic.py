@@ -1,0 +1,91 @@
+"""Host-side pieces around the kernel: config access, pose math, checkpoint format, handler errors."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import nwe_amd
+from nwe_amd import camera_poses, config
+from nwe_amd.handler import load_checkpoint, pinhole_intrinsics
+from nwe_amd.renderer import net_shape, normalize_state_dict
+from oracle import nerf_oracle as O
+
+
+def test_config_keys_and_products():
+    cfg = config.Config.for_office("office_tokyo")
+    assert cfg.get_param(("rendering", "n_samples"), int) == 64
+    assert cfg.get_param(("rendering", "n_importance"), int) == 128
+    assert config.parse_product(cfg.get_param(("inference", "chunk"), str)) == 8192       # "1024*8", no eval()
+    assert config.parse_product(cfg.get_param(("model", "net_chunk"), str)) == 32768
+    assert cfg.get_param(("rendering", "depth_range"), list) == [0.1, 10.0]
+    assert cfg.get_param(("experiment", "missing"), bool, default=False) is False
+    with pytest.raises(config.ConfigError):
+        cfg.get_param(("rendering", "nope"), int)
+    with pytest.raises(config.ConfigError):
+        config.Config(None).get_param(("a",), int)
+    assert not issubclass(config.ConfigError, Exception)            # BaseException, like config_parser.py:5
+    for office in ("office_new_york", "office_geneve", "office_belgrade"):
+        assert config.Config.for_office(office).get_param(("model", "net_width"), int) == 256
+
+
+def test_intrinsics_match_handler():
+    fx, fy, cx, cy = pinhole_intrinsics(240, 320)
+    assert fx == 320 / 2.0 / math.tan(math.radians(45.0)) and fy == fx            # fy derives from the WIDTH
+    assert (cx, cy) == (159.5, 119.5)
+    assert pinhole_intrinsics(800, 800) == O.intrinsics(800, 800)
+
+
+def test_pose_helper_closed_forms():
+    C = nwe_amd.COORD
+    init = C(x=0.0, y=-0.5, z=-0.75 / np.cos(-10 / 180 * np.pi), pitch=-90.0)
+    p = nwe_amd.get_camera_poses_from_list_of_coordinates(init, [C(), C(yaw=-30.0), C(yaw=90.0), C(pitch=30.0)])
+    assert p.shape == (4, 4, 4) and p.dtype == torch.float32
+    np.testing.assert_allclose(p[0, :3, :3], [[1, 0, 0], [0, 0, 1], [0, -1, 0]], atol=1e-6)
+    np.testing.assert_allclose(p[0, :3, 3], [0, -0.76157, 0.5], atol=1e-5)        # translation is R @ [x, y, z]
+    np.testing.assert_allclose(p[1, :3, :3], [[0.8660254, 0, 0.5], [-0.5, 0, 0.8660254], [0, -1, 0]], atol=1e-6)
+    for k in range(4):                                                             # rotations stay orthonormal
+        R = p[k, :3, :3].double().numpy()
+        np.testing.assert_allclose(R @ R.T, np.eye(3), atol=1e-6)
+        assert np.array_equal(p[k, :3, 3].numpy(), p[0, :3, 3].numpy())            # local turns keep the position
+    # the oracle's independent restatement agrees bit for bit
+    ref = O.camera_pose(tuple(init), (0, 0, 0, -30.0, 0.0, 0.0))
+    assert torch.equal(ref[0], p[1])
+
+
+def test_checkpoint_format_roundtrip(tmp_path):
+    """nerf_replica_training_handler.py:404-407 layout, keys without the leading underscore (handler.py:150-164)."""
+    sd_c = nwe_amd.synthetic.make_state_dict(3, 4, 128)
+    sd_f = nwe_amd.synthetic.make_state_dict(4, 4, 128)
+    strip = lambda sd: {k[1:]: torch.from_numpy(v) for k, v in sd.items()}
+    path = os.path.join(tmp_path, "model.ckpt")
+    torch.save({"global_step": 7, "network_coarse_state_dict": strip(sd_c), "network_fine_state_dict": strip(sd_f),
+                "optimizer_state_dict": {}}, path)
+    c, f = load_checkpoint(path)
+    nc = normalize_state_dict(c)
+    assert net_shape(nc) == (4, 128, 63, 27, -1)
+    assert all(np.array_equal(nc[k], sd_c[k]) for k in sd_c)
+    assert net_shape(normalize_state_dict(nwe_amd.synthetic.make_state_dict(1, 8, 256))) == (8, 256, 63, 27, 4)
+
+
+def test_handler_errors_without_gpu():
+    h = nwe_amd.NeRFReplicaInferenceHandler("office_geneve", "/nonexistent/model.ckpt")
+    assert h.image_size == (240, 320)
+    with pytest.raises(RuntimeError, match="Checkpoint path: /nonexistent/model.ckpt for model cannot be found!"):
+        h.initialize_models()
+    with pytest.raises(RuntimeError, match="initialize_models"):
+        h.render(np.eye(4, dtype=np.float32))
+    with pytest.raises(FileNotFoundError):
+        nwe_amd.NeRFReplicaInferenceHandler("office_nowhere", "x")
+
+
+def test_synthetic_weights_are_deterministic():
+    a = nwe_amd.synthetic.make_state_dict(1000, 8, 256)
+    b = nwe_amd.synthetic.make_state_dict(1000, 8, 256)
+    assert all(np.array_equal(a[k], b[k]) for k in a)
+    assert sum(v.size for v in a.values()) == 595844
+    assert sum(v.size for v in nwe_amd.synthetic.make_state_dict(1, 4, 128).values()) == 84548
+    assert abs(float(a["_pts_linears.3.weight"].max()) - 2 / 16) < 1e-3
+    fog = nwe_amd.synthetic.thin_fog(a)
+    assert np.all(fog["_alpha_linear.bias"] == np.float32(0.08)) and np.array_equal(fog["_rgb_linear.weight"], a["_rgb_linear.weight"])
