@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libnwe_hip.so")
+LIB_PATH = os.environ.get("NWE_LIB") or os.path.join(_HERE, "libnwe_hip.so")   # NWE_LIB: timing experiments with variant builds
 
 NWE_OK, NWE_ERR_INVALID, NWE_ERR_UNSUPPORTED, NWE_ERR_HIP, NWE_ERR_STATE = 0, 1, 2, 3, 4
 NET_COARSE, NET_FINE = 0, 1

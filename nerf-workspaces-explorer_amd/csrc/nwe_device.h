@@ -32,6 +32,7 @@ struct RenderArgs {
     const float* u_vals;
     const float* z_fine_in;  // test hook: fine depths [n_rays, ns+ni] instead of importance sampling
     int n_samples, n_importance;
+    int dbg;                 // timing experiments only (NWE_DEBUG env): 1 = no weight loads, 2 = no barriers
     nwe_outputs out;
 };
 

@@ -49,16 +49,33 @@ constexpr int kRaysPerWave = 32;
 constexpr float kLoScale = 2048.f;        // 2^kLoShift
 constexpr float kLoInv = 1.f / 2048.f;
 
-// Split 16 fp32 values (one 32x32 accumulator tile column) into the B fragments of two k-steps.
-// value -> hi = fp16(v), lo = fp16((v - hi) * 2^11).  Register r of the tile is element r&7 of k-step r>>3.
+// A 32-row tile whose accumulators are complete but whose epilogue (bias, ReLU, fp16 hi/lo split into the B
+// fragments of the next layer) has not run yet.  The epilogue of tile t is issued piecewise BETWEEN the MFMAs of
+// tile t+1 (a wave issues in order: VALU placed between two MFMAs executes while the matrix pipe works), so two
+// of these alternate.  The bias is read into registers when the tile starts and consumed one tile later, which
+// also keeps its LDS latency off the MFMA chain.
+struct Pend {
+    f16v a1, a2;      // hi.hi products / the two 2^-11 cross products
+    float4 bias[4];   // register 4g+i holds row 8g + 4h + i -> bias[g].{x,y,z,w}
+};
+
+__device__ __forceinline__ float pend_value(const Pend& t, int r, bool x3) {
+    const float4 b = t.bias[r >> 2];
+    const float bb = (r & 3) == 0 ? b.x : ((r & 3) == 1 ? b.y : ((r & 3) == 2 ? b.z : b.w));
+    const float base = t.a1[r] + bb;
+    return x3 ? __builtin_fmaf(t.a2[r], kLoInv, base) : base;
+}
+
+// Epilogue of elements 2p, 2p+1 of a pending tile: value -> max(value, lower) -> hi = fp16(v), lo = fp16((v-hi)*2^11).
+// Register r of the tile is element r&7 of the (r>>3)-th of its two output k-steps.
 template <bool X3>
-__device__ __forceinline__ void split_tile(const f16v& v, h8& hi0, h8& lo0, h8& hi1, h8& lo1) {
+__device__ __forceinline__ void finish_pair(const Pend& t, int p, float lower, h8& hi0, h8& lo0, h8& hi1, h8& lo1) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const _Float16 h = (_Float16)v[r];
-        _Float16 l = (_Float16)0.f;
-        if (X3) l = (_Float16)((v[r] - (float)h) * kLoScale);
-        if (r < 8) { hi0[r] = h; lo0[r] = l; } else { hi1[r - 8] = h; lo1[r - 8] = l; }
+    for (int e = 2 * p; e < 2 * p + 2; ++e) {
+        const float v = fmaxf(pend_value(t, e, X3), lower);
+        const _Float16 h = (_Float16)v;
+        const _Float16 l = X3 ? (_Float16)((v - (float)h) * kLoScale) : (_Float16)0.f;
+        if (e < 8) { hi0[e] = h; lo0[e] = l; } else { hi1[e - 8] = h; lo1[e - 8] = l; }
     }
 }
 
@@ -73,91 +90,172 @@ __device__ __forceinline__ void mma3(const h8& a_hi, const h8& a_lo, const h8& x
 }
 
 // The weight stream of one network, walked chunk by chunk through two LDS buffers.
+//
+// LDS-DMA goes through inline asm: hipcc's waitcnt pass treats a builtin global_load_lds as an LDS store that may
+// alias every later ds_read of the same array and drains vmcnt(0) in front of the first one, which would serialise
+// the prefetch with the compute it is meant to hide behind.  The asm form is invisible to that pass; completion is
+// waited for by hand in advance() (s_waitcnt vmcnt(0) + barrier).  M0 carries the wave-uniform LDS destination and
+// is compiler-reserved, so it is saved and restored inside the statement.  The 1-KiB pieces of the next chunk are
+// issued one per k-step BETWEEN the MFMAs of the current tile (a burst of ten back-to-back costs the wave several
+// hundred cycles of issue during which its matrix pipe idles).
 template <int CHUNK_BYTES>
 struct Walker {
     const uint8_t* stream;
-    uint32_t next_tile;   // first tile of the next chunk to issue
+    uint32_t next_tile;    // first tile of the next chunk to issue
     char* buf0;
-    int parity;           // buffer the next issue writes
-    int wave, lane;
+    int parity;            // buffer the next chunk is written to
+    int wave, lane, dbg;
+    const uint8_t* i_src;  // issue cursor of this wave: per-lane source, LDS destination, pieces left
+    uint32_t i_dst;
+    int i_left;
 
-    __device__ __forceinline__ void start(const uint8_t* s) { stream = s; next_tile = 0; }
-    __device__ __forceinline__ void issue(int ntiles) {
-        char* dst = buf0 + parity * CHUNK_BYTES;
-        const uint8_t* src = stream + (size_t)next_tile * kTileBytes + lane * 16;
-        for (int t = wave; t < ntiles; t += kWaves) {
-            __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(src + (size_t)t * kTileBytes),
-                                             (LDS_AS void*)(dst + t * kTileBytes), 16, 0, 0);
-        }
+    __device__ __forceinline__ void start(const uint8_t* s) { stream = s; next_tile = 0; i_left = 0; }
+    __device__ __forceinline__ void begin(int ntiles) {
+        i_dst = (uint32_t)(uintptr_t)(LDS_AS char*)(buf0 + parity * CHUNK_BYTES) + wave * kTileBytes;
+        i_src = stream + ((size_t)next_tile + wave) * kTileBytes + lane * 16;
+        i_left = (dbg & 1) ? 0 : (ntiles - wave + kWaves - 1) / kWaves;
         next_tile += ntiles;
         parity ^= 1;
     }
-    // Make the chunk issued last visible to every wave, start the next one, return the visible chunk.
+    __device__ __forceinline__ void issue_one() {
+        if (i_left > 0) {
+            const uint32_t dst = __builtin_amdgcn_readfirstlane(i_dst);
+            uint32_t keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(i_src), "s"(dst) : "memory");
+            i_src += kWaves * kTileBytes;
+            i_dst += kWaves * kTileBytes;
+            --i_left;
+        }
+    }
+    __device__ __forceinline__ void issue_rest() {
+        while (i_left > 0) issue_one();
+    }
+    // Make the chunk issued last visible to every wave and return it; then name the next chunk to stream.
     __device__ __forceinline__ const char* advance(int next_ntiles) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        issue_rest();
+        if (!(dbg & 2)) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
         const char* cur = buf0 + (parity ^ 1) * CHUNK_BYTES;
-        if (next_ntiles > 0) issue(next_ntiles);
+        if (next_ntiles > 0) begin(next_ntiles);
         return cur;
     }
 };
 
-// One 32-row tile: acc = bias + sum over the chunk's k-steps.  Chunk = [bias tile][optional NKG gamma
-// k-steps][NKH hidden k-steps], each k-step = hi tile then lo tile, each tile lane-linear (16 B/lane).
-template <int NKG, int NKH, bool X3>
-__device__ __forceinline__ void tile_mma(const char* chunk, int lane, bool use_g, const h8* Ghi, const h8* Glo,
-                                         const h8* Xhi, const h8* Xlo, f16v& acc1, f16v& acc2) {
+// NK k-steps of one tile with the A fragments (hi, lo tile pairs at p, lane-linear) software-pipelined two
+// k-steps ahead of their MFMAs, and, if PEND, the epilogue of the previous tile spread over the k-steps (pairs
+// [8s/NK, 8(s+1)/NK) are finished BEFORE the MFMAs of k-step s, so a pending tile that feeds this tile's last two
+// k-steps is complete in time).  FIRST: the accumulators start from the literal zero of the first MFMAs.
+template <int NK, bool X3, bool PEND, bool FIRST, bool ISSUE, class WalkerT>
+__device__ __forceinline__ void ksteps(WalkerT& wk, const char* p, const h8* Xhi, const h8* Xlo, f16v& acc1, f16v& acc2,
+                                       const Pend& prev, float lower, h8& y0h, h8& y0l, h8& y1h, h8& y1l) {
+    h8 fh[3], fl[3];
+#pragma unroll
+    for (int s = 0; s < 2 && s < NK; ++s) {
+        fh[s] = *reinterpret_cast<const h8*>(p + (2 * s) * kTileBytes);
+        if (X3) fl[s] = *reinterpret_cast<const h8*>(p + (2 * s + 1) * kTileBytes);
+    }
+#pragma unroll
+    for (int s = 0; s < NK; ++s) {
+        if (ISSUE) wk.issue_one();
+        if (s + 2 < NK) {
+            fh[(s + 2) % 3] = *reinterpret_cast<const h8*>(p + (2 * (s + 2)) * kTileBytes);
+            if (X3) fl[(s + 2) % 3] = *reinterpret_cast<const h8*>(p + (2 * (s + 2) + 1) * kTileBytes);
+        }
+        if (PEND) {
+#pragma unroll
+            for (int q = (8 * s) / NK; q < (8 * (s + 1)) / NK; ++q) finish_pair<X3>(prev, q, lower, y0h, y0l, y1h, y1l);
+        }
+        if (FIRST && s == 0) {
+            f16v zero;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) zero[r] = 0.f;
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[0], Xhi[0], zero, 0, 0, 0);
+            if (X3) {
+                acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fl[0], Xhi[0], zero, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[0], Xlo[0], acc2, 0, 0, 0);
+            }
+        } else {
+            mma3<X3>(fh[s % 3], fl[s % 3], Xhi[s], Xlo[s], acc1, acc2);
+        }
+        // Pin the issue order of this k-step (LLVM SchedGroupMask: 0x100 DS read, 0x8 MFMA, 0x2 VALU): the fragment
+        // reads of k-step s+2, then each MFMA followed by a few epilogue VALU ops that execute while the matrix pipe
+        // works.  Without this hipcc sinks the reads next to their use and clusters the epilogue.
+        if (s + 2 < NK) __builtin_amdgcn_sched_group_barrier(0x100, X3 ? 2 : 1, 0);
+        constexpr int V = PEND ? ((NK >= 16) ? (X3 ? 4 : 10) : ((NK >= 8) ? (X3 ? 7 : 16) : 14)) : 0;
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        if (V) __builtin_amdgcn_sched_group_barrier(0x002, V, 0);
+        if (X3) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if (V) __builtin_amdgcn_sched_group_barrier(0x002, V, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if (V) __builtin_amdgcn_sched_group_barrier(0x002, V, 0);
+        }
+    }
+    // Keep the epilogue HERE: its results are only consumed by the next layer, so without a use at this point
+    // LLVM sinks the whole epilogue of every tile of a layer to the layer's end (and keeps all their accumulators
+    // alive), which is exactly the un-overlapped VALU block this structure is meant to remove.
+    if (PEND) asm volatile("" : "+v"(y0h), "+v"(y0l), "+v"(y1h), "+v"(y1l));
+}
+
+// One 32-row tile.  Chunk = [bias tile][NKH k-steps over X][NKG gamma k-steps if use_g][NKD k-steps over D],
+// each k-step = hi tile then lo tile, each tile lane-linear (16 B per lane).  The pieces of the next chunk are
+// issued from inside the X segment.
+template <int NKG, int NKH, int NKD, bool X3, bool PEND, class WalkerT>
+__device__ __forceinline__ void tile_mma(WalkerT& wk, const char* chunk, int lane, bool use_g, const h8* Ghi, const h8* Glo,
+                                         const h8* Xhi, const h8* Xlo, const h8* Dhi, const h8* Dlo, Pend& cur, const Pend& prev,
+                                         float lower, h8& y0h, h8& y0l, h8& y1h, h8& y1l) {
     const float4* bp = reinterpret_cast<const float4*>(chunk);
     const int h = lane >> 5;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {   // register 4g+i holds row 8g + 4h + i
-        const float4 b = bp[2 * g + h];
-        acc1[4 * g + 0] = b.x; acc1[4 * g + 1] = b.y; acc1[4 * g + 2] = b.z; acc1[4 * g + 3] = b.w;
-    }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
+    for (int g = 0; g < 4; ++g) cur.bias[g] = bp[2 * g + h];
+    // the 4 bias reads and the fragment reads of the first two k-steps go first
+    __builtin_amdgcn_sched_group_barrier(0x100, 4 + (X3 ? 2 : 1) * (NKH < 2 ? NKH : 2), 0);
     const char* p = chunk + kTileBytes + lane * 16;
+    ksteps<NKH, X3, PEND, true, true>(wk, p, Xhi, Xlo, cur.a1, cur.a2, prev, lower, y0h, y0l, y1h, y1l);
+    p += NKH * 2 * kTileBytes;
     if (NKG > 0) {
         if (use_g) {
-#pragma unroll
-            for (int s = 0; s < NKG; ++s) {
-                const h8 a_hi = *reinterpret_cast<const h8*>(p + (2 * s) * kTileBytes);
-                const h8 a_lo = *reinterpret_cast<const h8*>(p + (2 * s + 1) * kTileBytes);
-                mma3<X3>(a_hi, a_lo, Ghi[s], Glo[s], acc1, acc2);
-            }
-            p += NKG * 2 * kTileBytes;
+            h8 d0, d1, d2, d3;
+            ksteps<NKG, X3, false, false, false>(wk, p, Ghi, Glo, cur.a1, cur.a2, prev, lower, d0, d1, d2, d3);
         }
     }
-#pragma unroll
-    for (int s = 0; s < NKH; ++s) {
-        const h8 a_hi = *reinterpret_cast<const h8*>(p + (2 * s) * kTileBytes);
-        const h8 a_lo = *reinterpret_cast<const h8*>(p + (2 * s + 1) * kTileBytes);
-        mma3<X3>(a_hi, a_lo, Xhi[s], Xlo[s], acc1, acc2);
+    if (NKD > 0) {
+        h8 d0, d1, d2, d3;
+        ksteps<NKD, X3, false, false, false>(wk, p, Dhi, Dlo, cur.a1, cur.a2, prev, lower, d0, d1, d2, d3);
     }
 }
 
-template <bool X3>
-__device__ __forceinline__ f16v finish(const f16v& acc1, const f16v& acc2, float lower) {
-    f16v v;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        float x = X3 ? __builtin_fmaf(acc2[r], kLoInv, acc1[r]) : acc1[r];
-        v[r] = fmaxf(x, lower);
-    }
-    return v;
-}
-
-// A full layer: NT row tiles, input = [optional gamma k-steps] + NKH k-steps of X, output split into Y.
-template <int NT, int NKG, int NKH, bool X3, class WalkerT>
+// A full layer of NT tiles reading X (+ gamma k-steps) and writing Y.  Tile rt accumulates into P[rt&1] while the
+// epilogue of the tile before it runs: for rt = 0 that is the LAST tile of the previous layer (in P1, destined for
+// k-steps 2*NT-2, 2*NT-1 of X itself), for rt > 0 tile rt-1 of this layer (destined for Y).  On return P1 holds
+// this layer's last tile, still pending.
+template <int NT, int NKG, int NKH, bool X3, bool PEND0, class WalkerT>
 __device__ __forceinline__ void layer(WalkerT& wk, int lane, bool use_g, int tiles_this, int tiles_after, const h8* Ghi,
-                                      const h8* Glo, const h8* Xhi, const h8* Xlo, h8* Yhi, h8* Ylo, float lower) {
+                                      const h8* Glo, h8* Xhi, h8* Xlo, h8* Yhi, h8* Ylo, Pend& P0, Pend& P1, float lower_prev,
+                                      float lower) {
+    static_assert(NT % 2 == 0, "tiles per layer must be even (accumulator ping-pong)");
 #pragma unroll
     for (int rt = 0; rt < NT; ++rt) {
         const char* chunk = wk.advance(rt + 1 < NT ? tiles_this : tiles_after);
-        f16v acc1, acc2;
-        tile_mma<NKG, NKH, X3>(chunk, lane, use_g, Ghi, Glo, Xhi, Xlo, acc1, acc2);
-        const f16v v = finish<X3>(acc1, acc2, lower);
-        split_tile<X3>(v, Yhi[2 * rt], Ylo[2 * rt], Yhi[2 * rt + 1], Ylo[2 * rt + 1]);
+        Pend& cur = (rt & 1) ? P1 : P0;
+        Pend& prev = (rt & 1) ? P0 : P1;
+        if (rt == 0) {
+            if constexpr (PEND0) {
+                constexpr int L = 2 * NT - 2;   // the previous layer has as many tiles as X has k-step pairs
+                tile_mma<NKG, NKH, 0, X3, true>(wk, chunk, lane, use_g, Ghi, Glo, Xhi, Xlo, nullptr, nullptr, cur, prev, lower_prev,
+                                                Xhi[L], Xlo[L], Xhi[L + 1], Xlo[L + 1]);
+            } else {
+                h8 d0, d1, d2, d3;
+                tile_mma<NKG, NKH, 0, X3, false>(wk, chunk, lane, use_g, Ghi, Glo, Xhi, Xlo, nullptr, nullptr, cur, prev, lower_prev,
+                                                 d0, d1, d2, d3);
+            }
+        } else {
+            tile_mma<NKG, NKH, 0, X3, true>(wk, chunk, lane, use_g, Ghi, Glo, Xhi, Xlo, nullptr, nullptr, cur, prev, lower,
+                                            Yhi[2 * rt - 2], Ylo[2 * rt - 2], Yhi[2 * rt - 1], Ylo[2 * rt - 1]);
+        }
     }
 }
 
@@ -197,66 +295,70 @@ __device__ __forceinline__ void encode(float vx, float vy, float vz, int h, h8* 
 }
 
 // One MLP evaluation for the wave's 32 points.  nerf/models/nerf_model.py:45-83.
-// Trunk layers 1..D-1 and the feature layer run as (D/2) pairs A->B, B->A so that the two activation
-// register sets keep fixed names inside a rolled loop.
+// Trunk layers 1..D-1 and the feature layer run as (D/2) pairs A->B, B->A so that the two activation register
+// sets keep fixed names inside a rolled loop; every tile's epilogue is deferred into the next tile (see Pend).
 template <int W, int D, int SKIP, bool X3, class WalkerT>
-__device__ __forceinline__ void mlp_eval(WalkerT& wk, int lane, const h8* Ghi, const h8* Glo, const h8* GDhi,
-                                         const h8* GDlo, float& o_r, float& o_g, float& o_b, float& o_s) {
+__device__ __forceinline__ void mlp_eval(WalkerT& wk, int lane, h8* Ghi, h8* Glo, const h8* GDhi, const h8* GDlo, float& o_r,
+                                         float& o_g, float& o_b, float& o_s) {
     using S = Shape<W>;
     static_assert(D % 2 == 0, "trunk depth must be even");
     static_assert(SKIP < 0 || SKIP % 2 == 0, "skip layer index must be even");
+    static_assert(S::NT % 2 == 0 && S::NTV % 2 == 0, "tile counts must be even");
     h8 Ahi[S::KH], Alo[S::KH], Bhi[S::KH], Blo[S::KH];
+    Pend P0, P1;
     constexpr int NPAIR = D / 2;
     constexpr int SKIP_PAIR = SKIP < 0 ? -1 : SKIP / 2;   // pair whose first layer takes [gamma, h]
     auto first_tiles = [&](int pair) { return pair == SKIP_PAIR ? S::T_S : S::T_H; };
 
-    // layer 0: gamma(x) -> A
-    layer<S::NT, 0, S::KG, X3>(wk, lane, false, S::T_L0, first_tiles(0), nullptr, nullptr, Ghi, Glo, Ahi, Alo, 0.f);
+    // layer 0: gamma(x) -> A (nothing pending in front of its first tile)
+    layer<S::NT, 0, S::KG, X3, false>(wk, lane, false, S::T_L0, first_tiles(0), nullptr, nullptr, Ghi, Glo, Ahi, Alo, P0, P1, 0.f, 0.f);
 
-    float sigma = 0.f;
 #pragma unroll 1
     for (int pair = 0; pair < NPAIR; ++pair) {
         const bool use_g = pair == SKIP_PAIR;
         const bool last = pair == NPAIR - 1;
-        // first of pair: A (+gamma) -> B, ReLU
-        layer<S::NT, S::KG, S::KH, X3>(wk, lane, use_g, first_tiles(pair), S::T_H, Ghi, Glo, Ahi, Alo, Bhi, Blo, 0.f);
+        // first of pair: A (+gamma) -> B, ReLU.  Its first tile finishes the pending last tile of A (ReLU: the
+        // producer is layer 0 or a non-final second-of-pair layer).
+        layer<S::NT, S::KG, S::KH, X3, true>(wk, lane, use_g, first_tiles(pair), S::T_H, Ghi, Glo, Ahi, Alo, Bhi, Blo, P0, P1, 0.f, 0.f);
         // second of pair: B -> A; the last pair's second layer is _feature_linear (no ReLU, nerf_model.py:64)
         const int after = last ? S::T_H /* alpha tile */ : first_tiles(pair + 1);
-        layer<S::NT, 0, S::KH, X3>(wk, lane, false, S::T_H, after, nullptr, nullptr, Bhi, Blo, Ahi, Alo,
-                                   last ? -INFINITY : 0.f);
-        if (last) {   // _alpha_linear on the same input B (nerf_model.py:63); rows 0 and 4 of its tile both hold it
-            const char* chunk = wk.advance(S::T_V);
-            f16v acc1, acc2;
-            tile_mma<0, S::KH, X3>(chunk, lane, false, nullptr, nullptr, Bhi, Blo, acc1, acc2);
-            sigma = X3 ? __builtin_fmaf(acc2[0], kLoInv, acc1[0]) : acc1[0];
-        }
+        layer<S::NT, 0, S::KH, X3, true>(wk, lane, false, S::T_H, after, nullptr, nullptr, Bhi, Blo, Ahi, Alo, P0, P1, 0.f,
+                                         last ? -INFINITY : 0.f);
     }
-    // view layer: [feature (A), gamma(d)] -> B[0..KV), ReLU (nerf_model.py:66-70)
+    constexpr int L = 2 * S::NT - 2;
+    // _alpha_linear on B, the input of _feature_linear (nerf_model.py:63); meanwhile the last feature tile (P1) is
+    // finished into A without ReLU.  Rows 0 and 4 of the alpha tile both hold the single output row.
+    {
+        const char* chunk = wk.advance(S::T_V);
+        tile_mma<0, S::KH, 0, X3, true>(wk, chunk, lane, false, nullptr, nullptr, Bhi, Blo, nullptr, nullptr, P0, P1, -INFINITY,
+                                        Ahi[L], Alo[L], Ahi[L + 1], Alo[L + 1]);
+    }
+    const float sigma = pend_value(P0, 0, X3);
+    // view layer: [feature (A), gamma(d)] -> B[0..KV), ReLU (nerf_model.py:66-70); tile rt accumulates in P[(rt+1)&1]
 #pragma unroll
     for (int rt = 0; rt < S::NTV; ++rt) {
         const char* chunk = wk.advance(rt + 1 < S::NTV ? S::T_V : S::T_RGB);
-        f16v acc1, acc2;
-        tile_mma<0, S::KH, X3>(chunk, lane, false, nullptr, nullptr, Ahi, Alo, acc1, acc2);
-        // gamma(d) k-steps follow the hidden ones in the chunk
-        const char* p = chunk + (1 + 2 * S::KH) * kTileBytes + lane * 16;
-#pragma unroll
-        for (int s = 0; s < S::KD; ++s) {
-            const h8 a_hi = *reinterpret_cast<const h8*>(p + (2 * s) * kTileBytes);
-            const h8 a_lo = *reinterpret_cast<const h8*>(p + (2 * s + 1) * kTileBytes);
-            mma3<X3>(a_hi, a_lo, GDhi[s], GDlo[s], acc1, acc2);
+        Pend& cur = (rt & 1) ? P0 : P1;
+        Pend& prev = (rt & 1) ? P1 : P0;
+        if (rt == 0) {
+            h8 d0, d1, d2, d3;   // the alpha tile (P0) has no activation output
+            tile_mma<0, S::KH, S::KD, X3, false>(wk, chunk, lane, false, nullptr, nullptr, Ahi, Alo, GDhi, GDlo, cur, prev, 0.f, d0, d1, d2, d3);
+        } else {
+            tile_mma<0, S::KH, S::KD, X3, true>(wk, chunk, lane, false, nullptr, nullptr, Ahi, Alo, GDhi, GDlo, cur, prev, 0.f,
+                                                Bhi[2 * rt - 2], Blo[2 * rt - 2], Bhi[2 * rt - 1], Blo[2 * rt - 1]);
         }
-        const f16v v = finish<X3>(acc1, acc2, 0.f);
-        split_tile<X3>(v, Bhi[2 * rt], Blo[2 * rt], Bhi[2 * rt + 1], Blo[2 * rt + 1]);
     }
-    // rgb head (nerf_model.py:74): rows 0..2 (and their copies 4..6 for the upper lane half)
+    // rgb head (nerf_model.py:74) in P1 while the last view tile (P0, NTV even) is finished into B; rows 0..2 and
+    // their copies 4..6 for the upper lane half
     {
+        constexpr int LV = 2 * S::NTV - 2;
         const char* chunk = wk.advance(0);
-        f16v acc1, acc2;
-        tile_mma<0, S::KV, X3>(chunk, lane, false, nullptr, nullptr, Bhi, Blo, acc1, acc2);
-        o_r = X3 ? __builtin_fmaf(acc2[0], kLoInv, acc1[0]) : acc1[0];
-        o_g = X3 ? __builtin_fmaf(acc2[1], kLoInv, acc1[1]) : acc1[1];
-        o_b = X3 ? __builtin_fmaf(acc2[2], kLoInv, acc1[2]) : acc1[2];
+        tile_mma<0, S::KV, 0, X3, true>(wk, chunk, lane, false, nullptr, nullptr, Bhi, Blo, nullptr, nullptr, P1, P0, 0.f, Bhi[LV], Blo[LV],
+                                        Bhi[LV + 1], Blo[LV + 1]);
     }
+    o_r = pend_value(P1, 0, X3);
+    o_g = pend_value(P1, 1, X3);
+    o_b = pend_value(P1, 2, X3);
     o_s = sigma;
 }
 
@@ -291,7 +393,7 @@ __global__ void __launch_bounds__(256) render_mfma_kernel(RenderArgs a, NetMfma 
     const Ray ray = load_ray(a, rclamp);
 
     Walker<S::CHUNK_BYTES> wk;
-    wk.buf0 = smem; wk.parity = 0; wk.wave = wave; wk.lane = lane;
+    wk.buf0 = smem; wk.parity = 0; wk.wave = wave; wk.lane = lane; wk.dbg = a.dbg;
 
     // gamma(d): once per ray (model_utils.py:23-25 re-embeds the same direction for every sample)
     h8 GDhi[S::KD], GDlo[S::KD];
@@ -316,7 +418,8 @@ __global__ void __launch_bounds__(256) render_mfma_kernel(RenderArgs a, NetMfma 
         }
         for (int s = 0; s < Stot; ++s) {
             wk.start(net.stream);
-            wk.issue(S::T_L0);   // first chunk of this evaluation flies while gamma(x) is computed
+            wk.begin(S::T_L0);   // first chunk of this evaluation flies while gamma(x) is computed
+            wk.issue_rest();
             if (s + 1 < Stot) {
                 if (pass == 0) z_next = coarse_z(ray, s_t[s + 1], s_omt[s + 1]);
                 else z_next = a.z_fine_in ? a.z_fine_in[rclamp * Stot + s + 1] : fs.next(ray);
