@@ -134,6 +134,11 @@ float nwe_last_kernel_ms(nwe_ctx *ctx);
  * has no MFMA kernel).  Layout: see DESIGN.md "weight stream".  Works on host-only contexts. */
 int64_t nwe_packed_bytes(const nwe_ctx *ctx, int which);
 int nwe_packed_copy(const nwe_ctx *ctx, int which, void *host_dst, int64_t bytes);
+/* The rest of the packed network: the per-chunk bias table (32 floats per chunk) and the power of two the packed
+ * weights are multiplied by. */
+int64_t nwe_packed_bias_count(const nwe_ctx *ctx, int which);
+int nwe_packed_bias_copy(const nwe_ctx *ctx, int which, float *host_dst, int64_t count);
+float nwe_packed_scale(const nwe_ctx *ctx, int which);
 
 /* Test hook: the NEXT nwe_render_rays call takes the fine-pass sample depths from z_dev (DEVICE [n_rays, S],
  * sorted per ray) instead of its own importance sampling; cleared after that call.  Lets a test feed the

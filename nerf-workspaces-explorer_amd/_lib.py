@@ -19,7 +19,8 @@ OUTPUT_FIELDS = ("rgb", "depth", "acc", "disp", "z_std", "rgb_coarse", "depth_co
 # every symbol include/nwe.h declares (tests/test_abi.py checks the library exports all of them)
 SYMBOLS = ("nwe_create", "nwe_destroy", "nwe_last_error", "nwe_set_network", "nwe_set_sampling", "nwe_render",
            "nwe_create_rays", "nwe_render_rays", "nwe_to8b", "nwe_flops_per_eval", "nwe_last_kernel_ms", "nwe_packed_bytes",
-           "nwe_packed_copy", "nwe_debug_set_fine_depths", "nwe_selftest")
+           "nwe_packed_copy", "nwe_packed_bias_count", "nwe_packed_bias_copy", "nwe_packed_scale",
+           "nwe_debug_set_fine_depths", "nwe_selftest")
 
 
 class Outputs(C.Structure):
@@ -56,6 +57,9 @@ def load() -> C.CDLL:
         "nwe_last_kernel_ms": (F, [P]),
         "nwe_packed_bytes": (I64, [P, I]),
         "nwe_packed_copy": (I, [P, I, P, I64]),
+        "nwe_packed_bias_count": (I64, [P, I]),
+        "nwe_packed_bias_copy": (I, [P, I, P, I64]),
+        "nwe_packed_scale": (F, [P, I]),
         "nwe_debug_set_fine_depths": (I, [P, P]),
         "nwe_selftest": (I, [P, C.POINTER(C.c_int32)]),
     }

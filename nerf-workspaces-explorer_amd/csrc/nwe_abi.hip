@@ -21,8 +21,11 @@ struct NetState {
     float* d_blob = nullptr;
     bool mfma_ok = false;
     std::vector<uint8_t> stream;   // MFMA kernel: 1-KiB tiles in consumption order
+    std::vector<float> bias_tab;   // MFMA kernel: 32 floats per chunk
+    float w_scale = 1.f;           // power of two the packed weights are multiplied by
     NetMfma mf = {};
     uint8_t* d_stream = nullptr;
+    float* d_bias = nullptr;
 };
 
 thread_local std::string g_create_error;
@@ -94,7 +97,7 @@ struct RowMap {   // which weight row feeds tile row i (or -1)
     }
 };
 
-void put_tile_pair(std::vector<uint8_t>& out, const float* w, int ld, const RowMap& rows, int rt, const Segment& sg, int s) {
+void put_tile_pair(std::vector<uint8_t>& out, const float* w, int ld, const RowMap& rows, int rt, const Segment& sg, int s, float scale) {
     const size_t base = out.size();
     out.resize(base + 2 * kTileBytes, 0);
     _Float16* hi = reinterpret_cast<_Float16*>(out.data() + base);
@@ -105,31 +108,41 @@ void put_tile_pair(std::vector<uint8_t>& out, const float* w, int ld, const RowM
         for (int j = 0; j < 8; ++j) {
             int col = sg.kind == 0 ? hidden_col(s, h, j) : gamma_col(sg.kind == 1 ? 5 : 2, s, h, j);
             float v = 0.f;
-            if (row >= 0 && col >= 0) v = w[(size_t)row * ld + sg.col_off + col];
+            if (row >= 0 && col >= 0) v = w[(size_t)row * ld + sg.col_off + col] * scale;   // power of two: exact
             const _Float16 vh = (_Float16)v;
             hi[lane * 8 + j] = vh;
-            lo[lane * 8 + j] = (_Float16)((v - (float)vh) * (float)(1 << kLoShift));
+            lo[lane * 8 + j] = (_Float16)(v - (float)vh);
         }
     }
 }
 
-void put_chunk(std::vector<uint8_t>& out, const float* w, const float* b, int ld, const RowMap& rows, int rt,
-               const std::vector<Segment>& segs) {
-    const size_t base = out.size();
-    out.resize(base + kTileBytes, 0);
-    float* bias = reinterpret_cast<float*>(out.data() + base);
-    for (int i = 0; i < 32; ++i) { const int r = rows(rt, i); bias[i] = r >= 0 ? b[r] : 0.f; }
+void put_chunk(NetState& n, const float* w, const float* b, int ld, const RowMap& rows, int rt, const std::vector<Segment>& segs) {
+    for (int i = 0; i < 32; ++i) { const int r = rows(rt, i); n.bias_tab.push_back(r >= 0 ? b[r] : 0.f); }
     for (const Segment& sg : segs)
-        for (int s = 0; s < sg.ksteps; ++s) put_tile_pair(out, w, ld, rows, rt, sg, s);
+        for (int s = 0; s < sg.ksteps; ++s) put_tile_pair(n.stream, w, ld, rows, rt, sg, s, n.w_scale);
 }
 
 // Stream order = the order mlp_eval() consumes chunks in.
 void pack_mfma(NetState& n, const float* const* w, const float* const* b) {
     const int D = n.D, W = n.W, KH = W / 16;
     n.stream.clear();
+    n.bias_tab.clear();
+    // One power-of-two scale for the whole network: the largest that keeps every scaled weight below 2^14, so that
+    // the lo halves (|lo| <= ulp(hi)/2) are fp16-normal for all but vanishing weights.  The kernel multiplies the
+    // accumulator by 1/scale before adding the bias; both scalings are exact.
+    const int in_dims[4] = {W + n.in_dir, W, W, W / 2}, out_dims[4] = {W / 2, W, 1, 3};
+    float wmax = 0.f;
+    for (int li = 0; li < D + 4; ++li) {
+        const size_t cnt = li < D ? (size_t)W * (li == 0 ? n.in_xyz : (li == n.skip + 1 ? W + n.in_xyz : W))
+                                  : (size_t)in_dims[li - D] * out_dims[li - D];
+        for (size_t k = 0; k < cnt; ++k) wmax = std::max(wmax, std::fabs(w[li][k]));
+    }
+    int e = 0;
+    if (wmax > 0.f && std::isfinite(wmax)) { e = 14 - (int)std::ceil(std::log2(wmax)); e = std::min(std::max(e, -14), 30); }
+    n.w_scale = std::ldexp(1.f, e);
     auto layer = [&](int li, int n_out, int ld, int n_tiles, int dup4, const std::vector<Segment>& segs) {
         RowMap rows{n_out, dup4};
-        for (int rt = 0; rt < n_tiles; ++rt) put_chunk(n.stream, w[li], b[li], ld, rows, rt, segs);
+        for (int rt = 0; rt < n_tiles; ++rt) put_chunk(n, w[li], b[li], ld, rows, rt, segs);
     };
     layer(0, W, n.in_xyz, W / 32, 0, {{1, 4, 0}});
     for (int i = 1; i < D; ++i) {
@@ -212,6 +225,8 @@ int check_ready(nwe_ctx* ctx, const nwe_outputs* out, int precision) {
         if (!ctx->net[0].mfma_ok || (ctx->ni > 0 && !ctx->net[1].mfma_ok))
             return fail(ctx, NWE_ERR_UNSUPPORTED,
                         "no MFMA kernel for this network shape (have 8x256 skip 4 and 4x128, 63/27 inputs); use NWE_PREC_F32");
+        if (ctx->ns > mfma_max_samples())
+            return fail(ctx, NWE_ERR_UNSUPPORTED, "the MFMA kernel supports n_samples <= 64; use NWE_PREC_F32");
     }
     return NWE_OK;
 }
@@ -262,7 +277,7 @@ void nwe_destroy(nwe_ctx* c) {
     if (!c) return;
     if (!c->host_only) {
         (void)hipSetDevice(c->device);
-        for (NetState& n : c->net) { if (n.d_blob) (void)hipFree(n.d_blob); if (n.d_stream) (void)hipFree(n.d_stream); }
+        for (NetState& n : c->net) { if (n.d_blob) (void)hipFree(n.d_blob); if (n.d_stream) (void)hipFree(n.d_stream); if (n.d_bias) (void)hipFree(n.d_bias); }
         if (c->d_t) (void)hipFree(c->d_t);
         if (c->d_poses) (void)hipFree(c->d_poses);
         if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -289,21 +304,27 @@ int nwe_set_network(nwe_ctx* c, int which, int depth, int width, int in_xyz, int
     n.flops = algo_flops(n);
     pack_f32(n, w, b);
     n.mfma_ok = mfma_supported(depth, width, in_xyz, in_dir, skip_layer);
-    if (n.mfma_ok) pack_mfma(n, w, b); else n.stream.clear();
+    if (n.mfma_ok) pack_mfma(n, w, b); else { n.stream.clear(); n.bias_tab.clear(); }
     n.mf = {};
     n.mf.D = depth; n.mf.W = width; n.mf.skip = skip_layer; n.mf.n_tiles = (int)(n.stream.size() / kTileBytes);
+    n.mf.n_chunks = (int)(n.bias_tab.size() / 32);
+    n.mf.inv_scale = 1.f / n.w_scale;
     if (!c->host_only) {
         HIPCHK(c, hipSetDevice(c->device));
         if (n.d_blob) { (void)hipFree(n.d_blob); n.d_blob = nullptr; }
         if (n.d_stream) { (void)hipFree(n.d_stream); n.d_stream = nullptr; }
+        if (n.d_bias) { (void)hipFree(n.d_bias); n.d_bias = nullptr; }
         HIPCHK(c, hipMalloc(&n.d_blob, n.blob.size() * sizeof(float)));
         HIPCHK(c, hipMemcpy(n.d_blob, n.blob.data(), n.blob.size() * sizeof(float), hipMemcpyHostToDevice));
         if (n.mfma_ok) {
             HIPCHK(c, hipMalloc(&n.d_stream, n.stream.size()));
             HIPCHK(c, hipMemcpy(n.d_stream, n.stream.data(), n.stream.size(), hipMemcpyHostToDevice));
+            HIPCHK(c, hipMalloc(&n.d_bias, n.bias_tab.size() * sizeof(float)));
+            HIPCHK(c, hipMemcpy(n.d_bias, n.bias_tab.data(), n.bias_tab.size() * sizeof(float), hipMemcpyHostToDevice));
         }
         n.f32.blob = n.d_blob;
         n.mf.stream = n.d_stream;
+        n.mf.bias = n.d_bias;
     }
     n.set = true;
     return NWE_OK;
@@ -413,6 +434,23 @@ int nwe_packed_copy(const nwe_ctx* c, int which, void* host_dst, int64_t bytes) 
     if (bytes != (int64_t)c->net[which].stream.size()) return NWE_ERR_INVALID;
     std::memcpy(host_dst, c->net[which].stream.data(), (size_t)bytes);
     return NWE_OK;
+}
+
+int64_t nwe_packed_bias_count(const nwe_ctx* c, int which) {
+    if (!c || which < 0 || which > 1 || !c->net[which].set) return 0;
+    return (int64_t)c->net[which].bias_tab.size();
+}
+
+int nwe_packed_bias_copy(const nwe_ctx* c, int which, float* host_dst, int64_t count) {
+    if (!c || which < 0 || which > 1 || !host_dst || !c->net[which].set) return NWE_ERR_INVALID;
+    if (count != (int64_t)c->net[which].bias_tab.size()) return NWE_ERR_INVALID;
+    std::memcpy(host_dst, c->net[which].bias_tab.data(), (size_t)count * sizeof(float));
+    return NWE_OK;
+}
+
+float nwe_packed_scale(const nwe_ctx* c, int which) {
+    if (!c || which < 0 || which > 1 || !c->net[which].set) return 0.f;
+    return c->net[which].w_scale;
 }
 
 int nwe_debug_set_fine_depths(nwe_ctx* c, const float* z_dev) {

@@ -24,8 +24,10 @@ void launch_render_f32(const RenderArgs& a, const NetF32& nc, const NetF32& nf, 
 
 // ---- MFMA kernel: a stream of 1-KiB tiles in consumption order (DESIGN.md "weight stream") -----
 struct NetMfma {
-    const uint8_t* stream;  // device
-    int n_tiles;
+    const uint8_t* stream;  // device: 1-KiB tiles, (hi, lo) per k-step, chunk after chunk
+    const float* bias;      // device: 32 floats per chunk (tile row i -> bias of the weight row it holds)
+    int n_tiles, n_chunks;
+    float inv_scale;        // weights are stored multiplied by 1/inv_scale (a power of two)
     int D, W, skip;
 };
 
@@ -35,7 +37,7 @@ bool mfma_supported(int D, int W, int in_xyz, int in_dir, int skip);
 bool launch_render_mfma(const RenderArgs& a, const NetMfma& nc, const NetMfma& nf, bool three_pass, hipStream_t stream);
 
 constexpr int kTileBytes = 1024;
-constexpr int kLoShift = 11;  // lo halves are stored as (x - hi) * 2^11 so they stay fp16-normal
+int mfma_max_samples();      // n_samples the MFMA kernel's per-wave LDS buffers are sized for
 
 // Self-test kernels (nwe_selftest.hip)
 int run_selftest(int32_t* report8, hipStream_t stream);

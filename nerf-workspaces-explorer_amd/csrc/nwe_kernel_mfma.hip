@@ -12,23 +12,30 @@
 //     ray on the lane and the features in the 16 registers, which is exactly the B-operand layout of
 //     the next layer (k order permuted; the packer permutes the weight columns to match), so
 //     activations never leave the register file between layers.
-//   * fp32-grade results from fp16 MFMA: every operand is split x = hi + lo*2^-11 (both fp16) and
-//     W.x ~= Whi.xhi + 2^-11 (Wlo.xhi + Whi.xlo); the 2^-11 terms get their own accumulator.
-//   * weights stream from L2 through two LDS buffers with LDS-DMA (global_load_lds_dwordx4), one
-//     chunk = one 32-row tile of a layer (bias tile + hi/lo tile per 16-wide k-step), prefetched one
-//     chunk ahead.
+//   * fp32-grade results from fp16 MFMA: every operand is split x = hi + lo (both fp16) and
+//     W.x ~= Whi.xhi + Wlo.xhi + Whi.xlo, three MFMAs into one fp32 accumulator.  Weights are scaled
+//     by a power of two at pack time so that their lo halves are fp16-normal; activation lo halves may
+//     be fp16-subnormal (absolute error <= 3e-8), which the matrix core honours (nwe_selftest).
+//   * weights stream from L2 through two LDS buffers with LDS-DMA (global_load_lds_dwordx4), one chunk
+//     = one 32-row tile of a layer (hi/lo tile per 16-wide k-step), issued one chunk ahead, piece by
+//     piece between the MFMAs of the current tile.
+//   * one wave per SIMD: the wave's own instruction issue is the scarce resource next to the matrix
+//     pipe, so everything around the MFMAs is kept to a handful of instructions per MFMA: the
+//     epilogue of tile t (bias, ReLU, hi/lo split) is interleaved with the MFMAs of tile t+1, LDS-DMA
+//     addressing is scalar, the A fragments are read three k-steps ahead.
 #include "nwe_host.h"
 
 namespace nwe {
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
-typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 typedef float f16v __attribute__((ext_vector_type(16)));
 
-#define GLOBAL_AS __attribute__((address_space(1)))
 #define LDS_AS __attribute__((address_space(3)))
 
-template <int W>
+constexpr int kWaves = 4;
+constexpr int kRaysPerWave = 32;
+
+template <int W, int D>
 struct Shape {
     static constexpr int NT = W / 32;    // 32-row tiles of a W-wide layer
     static constexpr int KH = W / 16;    // k-steps over a W-wide activation vector
@@ -36,56 +43,52 @@ struct Shape {
     static constexpr int KD = 2;         // k-steps over gamma(d) (27 -> 32 slots)
     static constexpr int NTV = W / 64;   // row tiles of the view layer (W/2 outputs)
     static constexpr int KV = W / 32;    // k-steps over the view layer output
-    static constexpr int T_L0 = 1 + 2 * KG;          // tiles per chunk: bias tile + (hi, lo) per k-step
-    static constexpr int T_H = 1 + 2 * KH;
-    static constexpr int T_S = 1 + 2 * (KG + KH);    // skip layer
-    static constexpr int T_V = 1 + 2 * (KH + KD);
-    static constexpr int T_RGB = 1 + 2 * KV;
-    static constexpr int CHUNK_BYTES = T_S * kTileBytes;
+    // LDS-DMA pieces (1 KiB tiles) per wave and chunk: (hi, lo) per k-step, split evenly over the 4 waves
+    static constexpr int N_L0 = 2 * KG / kWaves;
+    static constexpr int N_H = 2 * KH / kWaves;
+    static constexpr int N_S = 2 * (KH + KG) / kWaves;   // skip layer
+    static constexpr int N_V = 2 * (KH + KD) / kWaves;
+    static constexpr int N_RGB = 2 * KV / kWaves;
+    static constexpr int CHUNK_BYTES = N_S * kWaves * kTileBytes;
+    static constexpr int N_CHUNKS = NT + D * NT + 1 + NTV + 1;   // layer 0, D/2 pairs, alpha, views, rgb
 };
 
-constexpr int kWaves = 4;
-constexpr int kRaysPerWave = 32;
-constexpr float kLoScale = 2048.f;        // 2^kLoShift
-constexpr float kLoInv = 1.f / 2048.f;
-
-// A 32-row tile whose accumulators are complete but whose epilogue (bias, ReLU, fp16 hi/lo split into the B
+// A 32-row tile whose accumulator is complete but whose epilogue (scale, bias, ReLU, fp16 hi/lo split into the B
 // fragments of the next layer) has not run yet.  The epilogue of tile t is issued piecewise BETWEEN the MFMAs of
 // tile t+1 (a wave issues in order: VALU placed between two MFMAs executes while the matrix pipe works), so two
-// of these alternate.  The bias is read into registers when the tile starts and consumed one tile later, which
-// also keeps its LDS latency off the MFMA chain.
+// of these alternate.  The bias is read when the tile starts and consumed one tile later, which also keeps its
+// LDS latency off the MFMA chain.
 struct Pend {
-    f16v a1, a2;      // hi.hi products / the two 2^-11 cross products
+    f16v a;
     float4 bias[4];   // register 4g+i holds row 8g + 4h + i -> bias[g].{x,y,z,w}
 };
 
-__device__ __forceinline__ float pend_value(const Pend& t, int r, bool x3) {
+__device__ __forceinline__ float pend_value(const Pend& t, int r, float inv_scale) {
     const float4 b = t.bias[r >> 2];
     const float bb = (r & 3) == 0 ? b.x : ((r & 3) == 1 ? b.y : ((r & 3) == 2 ? b.z : b.w));
-    const float base = t.a1[r] + bb;
-    return x3 ? __builtin_fmaf(t.a2[r], kLoInv, base) : base;
+    return __builtin_fmaf(t.a[r], inv_scale, bb);
 }
 
-// Epilogue of elements 2p, 2p+1 of a pending tile: value -> max(value, lower) -> hi = fp16(v), lo = fp16((v-hi)*2^11).
+// Epilogue of elements 2p, 2p+1 of a pending tile: v = max(acc/scale + bias, lower), hi = fp16(v), lo = fp16(v - hi).
 // Register r of the tile is element r&7 of the (r>>3)-th of its two output k-steps.
 template <bool X3>
-__device__ __forceinline__ void finish_pair(const Pend& t, int p, float lower, h8& hi0, h8& lo0, h8& hi1, h8& lo1) {
+__device__ __forceinline__ void finish_pair(const Pend& t, int p, float inv_scale, float lower, h8& hi0, h8& lo0, h8& hi1,
+                                            h8& lo1) {
 #pragma unroll
     for (int e = 2 * p; e < 2 * p + 2; ++e) {
-        const float v = fmaxf(pend_value(t, e, X3), lower);
+        const float v = fmaxf(pend_value(t, e, inv_scale), lower);
         const _Float16 h = (_Float16)v;
-        const _Float16 l = X3 ? (_Float16)((v - (float)h) * kLoScale) : (_Float16)0.f;
+        const _Float16 l = X3 ? (_Float16)__builtin_fmaf((float)h, -1.f, v) : (_Float16)0.f;   // v_fma_mix: no separate cvt
         if (e < 8) { hi0[e] = h; lo0[e] = l; } else { hi1[e - 8] = h; lo1[e - 8] = l; }
     }
 }
 
 template <bool X3>
-__device__ __forceinline__ void mma3(const h8& a_hi, const h8& a_lo, const h8& x_hi, const h8& x_lo, f16v& acc1,
-                                     f16v& acc2) {
-    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, x_hi, acc1, 0, 0, 0);
+__device__ __forceinline__ void mma3(const h8& a_hi, const h8& a_lo, const h8& x_hi, const h8& x_lo, f16v& acc) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, x_hi, acc, 0, 0, 0);
     if (X3) {
-        acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo, x_hi, acc2, 0, 0, 0);
-        acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, x_lo, acc2, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo, x_hi, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, x_lo, acc, 0, 0, 0);
     }
 }
 
@@ -95,96 +98,97 @@ __device__ __forceinline__ void mma3(const h8& a_hi, const h8& a_lo, const h8& x
 // alias every later ds_read of the same array and drains vmcnt(0) in front of the first one, which would serialise
 // the prefetch with the compute it is meant to hide behind.  The asm form is invisible to that pass; completion is
 // waited for by hand in advance() (s_waitcnt vmcnt(0) + barrier).  M0 carries the wave-uniform LDS destination and
-// is compiler-reserved, so it is saved and restored inside the statement.  The 1-KiB pieces of the next chunk are
-// issued one per k-step BETWEEN the MFMAs of the current tile (a burst of ten back-to-back costs the wave several
-// hundred cycles of issue during which its matrix pipe idles).
+// is compiler-reserved, so it is saved and restored inside the statement.  Wave w streams the w-th quarter of a
+// chunk (n consecutive 1-KiB pieces): source = scalar base + lane*16, so a piece costs scalar instructions only.
 template <int CHUNK_BYTES>
 struct Walker {
     const uint8_t* stream;
-    uint32_t next_tile;    // first tile of the next chunk to issue
-    char* buf0;
-    int parity;            // buffer the next chunk is written to
-    int wave, lane, dbg;
-    const uint8_t* i_src;  // issue cursor of this wave: per-lane source, LDS destination, pieces left
-    uint32_t i_dst;
-    int i_left;
+    uint32_t next_tile;      // first tile of the next chunk to stream
+    uint32_t lds_chunks;     // LDS byte address of chunk buffer 0
+    const char* buf0;
+    const float* bias_tab;   // LDS bias table of the current network, 32 floats per chunk
+    int chunk;               // index of the chunk being consumed
+    int parity;              // buffer the next chunk is written to
+    int wave, dbg;
+    uint32_t lane_off;       // lane * 16
+    const uint8_t* blk_src;  // this wave's quarter of the chunk being streamed (uniform)
+    uint32_t blk_dst;
 
-    __device__ __forceinline__ void start(const uint8_t* s) { stream = s; next_tile = 0; i_left = 0; }
-    __device__ __forceinline__ void begin(int ntiles) {
-        i_dst = (uint32_t)(uintptr_t)(LDS_AS char*)(buf0 + parity * CHUNK_BYTES) + wave * kTileBytes;
-        i_src = stream + ((size_t)next_tile + wave) * kTileBytes + lane * 16;
-        i_left = (dbg & 1) ? 0 : (ntiles - wave + kWaves - 1) / kWaves;
-        next_tile += ntiles;
+    __device__ __forceinline__ void start(const uint8_t* s, const float* bias) {
+        stream = s; bias_tab = bias; next_tile = 0; chunk = -1;
+    }
+    __device__ __forceinline__ void begin(int n_per_wave) {
+        blk_src = stream + ((size_t)next_tile + (size_t)wave * n_per_wave) * kTileBytes;
+        blk_dst = lds_chunks + parity * CHUNK_BYTES + wave * n_per_wave * kTileBytes;
+        next_tile += n_per_wave * kWaves;
         parity ^= 1;
     }
-    __device__ __forceinline__ void issue_one() {
-        if (i_left > 0) {
-            const uint32_t dst = __builtin_amdgcn_readfirstlane(i_dst);
-            uint32_t keep;
-            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                         : "=&s"(keep) : "v"(i_src), "s"(dst) : "memory");
-            i_src += kWaves * kTileBytes;
-            i_dst += kWaves * kTileBytes;
-            --i_left;
-        }
+    __device__ __forceinline__ void piece(int i) {
+        if (dbg & 1) return;
+        const uint8_t* src = blk_src + (size_t)i * kTileBytes;
+        const uint32_t dst = blk_dst + i * kTileBytes;
+        uint32_t keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(lane_off), "s"(src), "s"(dst) : "memory");
     }
-    __device__ __forceinline__ void issue_rest() {
-        while (i_left > 0) issue_one();
-    }
-    // Make the chunk issued last visible to every wave and return it; then name the next chunk to stream.
-    __device__ __forceinline__ const char* advance(int next_ntiles) {
-        issue_rest();
+    // Make the chunk streamed last visible to every wave and return it.
+    __device__ __forceinline__ const char* advance() {
         if (!(dbg & 2)) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
         }
-        const char* cur = buf0 + (parity ^ 1) * CHUNK_BYTES;
-        if (next_ntiles > 0) begin(next_ntiles);
-        return cur;
+        ++chunk;
+        return buf0 + (parity ^ 1) * CHUNK_BYTES;
     }
 };
 
-// NK k-steps of one tile with the A fragments (hi, lo tile pairs at p, lane-linear) software-pipelined two
-// k-steps ahead of their MFMAs, and, if PEND, the epilogue of the previous tile spread over the k-steps (pairs
-// [8s/NK, 8(s+1)/NK) are finished BEFORE the MFMAs of k-step s, so a pending tile that feeds this tile's last two
-// k-steps is complete in time).  FIRST: the accumulators start from the literal zero of the first MFMAs.
-template <int NK, bool X3, bool PEND, bool FIRST, bool ISSUE, class WalkerT>
-__device__ __forceinline__ void ksteps(WalkerT& wk, const char* p, const h8* Xhi, const h8* Xlo, f16v& acc1, f16v& acc2,
-                                       const Pend& prev, float lower, h8& y0h, h8& y0l, h8& y1h, h8& y1l) {
-    h8 fh[3], fl[3];
+// NK k-steps of one tile with the A fragments (hi, lo tile pairs at p, lane-linear) read PD k-steps ahead of their
+// MFMAs and, if PEND, the epilogue of the previous tile spread over the k-steps (pairs [8s/NK, 8(s+1)/NK) are
+// finished BEFORE the MFMAs of k-step s, so a pending tile that feeds this tile's last two k-steps is complete in
+// time).  FIRST: the accumulator starts from the literal zero of the first MFMA.  NPC > 0: this wave's NPC (+2 if
+// `extra`) pieces of the next chunk are issued spread over the k-steps.
+template <int NK, bool X3, bool PEND, bool FIRST, int NPC, class WalkerT>
+__device__ __forceinline__ void ksteps(WalkerT& wk, const char* p, const h8* Xhi, const h8* Xlo, f16v& acc, const Pend& prev,
+                                       float inv_scale, float lower, bool extra, h8& y0h, h8& y0l, h8& y1h, h8& y1l) {
+    constexpr int PD = 3;
+    h8 fh[PD + 1], fl[PD + 1];
 #pragma unroll
-    for (int s = 0; s < 2 && s < NK; ++s) {
+    for (int s = 0; s < PD && s < NK; ++s) {
         fh[s] = *reinterpret_cast<const h8*>(p + (2 * s) * kTileBytes);
         if (X3) fl[s] = *reinterpret_cast<const h8*>(p + (2 * s + 1) * kTileBytes);
     }
 #pragma unroll
     for (int s = 0; s < NK; ++s) {
-        if (ISSUE) wk.issue_one();
-        if (s + 2 < NK) {
-            fh[(s + 2) % 3] = *reinterpret_cast<const h8*>(p + (2 * (s + 2)) * kTileBytes);
-            if (X3) fl[(s + 2) % 3] = *reinterpret_cast<const h8*>(p + (2 * (s + 2) + 1) * kTileBytes);
+        if (NPC > 0) {
+#pragma unroll
+            for (int i = (s * NPC + NK - 1) / NK; i < ((s + 1) * NPC + NK - 1) / NK; ++i) wk.piece(i);
+            if (s == NK - 1 && extra) { wk.piece(NPC); wk.piece(NPC + 1); }
+        }
+        if (s + PD < NK) {
+            fh[(s + PD) % (PD + 1)] = *reinterpret_cast<const h8*>(p + (2 * (s + PD)) * kTileBytes);
+            if (X3) fl[(s + PD) % (PD + 1)] = *reinterpret_cast<const h8*>(p + (2 * (s + PD) + 1) * kTileBytes);
         }
         if (PEND) {
 #pragma unroll
-            for (int q = (8 * s) / NK; q < (8 * (s + 1)) / NK; ++q) finish_pair<X3>(prev, q, lower, y0h, y0l, y1h, y1l);
+            for (int q = (8 * s) / NK; q < (8 * (s + 1)) / NK; ++q) finish_pair<X3>(prev, q, inv_scale, lower, y0h, y0l, y1h, y1l);
         }
         if (FIRST && s == 0) {
             f16v zero;
 #pragma unroll
             for (int r = 0; r < 16; ++r) zero[r] = 0.f;
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[0], Xhi[0], zero, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[0], Xhi[0], zero, 0, 0, 0);
             if (X3) {
-                acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fl[0], Xhi[0], zero, 0, 0, 0);
-                acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[0], Xlo[0], acc2, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fl[0], Xhi[0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[0], Xlo[0], acc, 0, 0, 0);
             }
         } else {
-            mma3<X3>(fh[s % 3], fl[s % 3], Xhi[s], Xlo[s], acc1, acc2);
+            mma3<X3>(fh[s % (PD + 1)], fl[s % (PD + 1)], Xhi[s], Xlo[s], acc);
         }
         // Pin the issue order of this k-step (LLVM SchedGroupMask: 0x100 DS read, 0x8 MFMA, 0x2 VALU): the fragment
-        // reads of k-step s+2, then each MFMA followed by a few epilogue VALU ops that execute while the matrix pipe
+        // reads of k-step s+PD, then each MFMA followed by a few epilogue VALU ops that execute while the matrix pipe
         // works.  Without this hipcc sinks the reads next to their use and clusters the epilogue.
-        if (s + 2 < NK) __builtin_amdgcn_sched_group_barrier(0x100, X3 ? 2 : 1, 0);
-        constexpr int V = PEND ? ((NK >= 16) ? (X3 ? 4 : 10) : ((NK >= 8) ? (X3 ? 7 : 16) : 14)) : 0;
+        if (s + PD < NK) __builtin_amdgcn_sched_group_barrier(0x100, X3 ? 2 : 1, 0);
+        constexpr int V = PEND ? ((NK >= 16) ? (X3 ? 2 : 6) : ((NK >= 8) ? (X3 ? 4 : 12) : 8)) : 0;
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         if (V) __builtin_amdgcn_sched_group_barrier(0x002, V, 0);
         if (X3) {
@@ -200,61 +204,66 @@ __device__ __forceinline__ void ksteps(WalkerT& wk, const char* p, const h8* Xhi
     if (PEND) asm volatile("" : "+v"(y0h), "+v"(y0l), "+v"(y1h), "+v"(y1l));
 }
 
-// One 32-row tile.  Chunk = [bias tile][NKH k-steps over X][NKG gamma k-steps if use_g][NKD k-steps over D],
-// each k-step = hi tile then lo tile, each tile lane-linear (16 B per lane).  The pieces of the next chunk are
-// issued from inside the X segment.
-template <int NKG, int NKH, int NKD, bool X3, bool PEND, class WalkerT>
-__device__ __forceinline__ void tile_mma(WalkerT& wk, const char* chunk, int lane, bool use_g, const h8* Ghi, const h8* Glo,
-                                         const h8* Xhi, const h8* Xlo, const h8* Dhi, const h8* Dlo, Pend& cur, const Pend& prev,
+// One 32-row tile.  Chunk = [NKH k-steps over X][NKG gamma k-steps if use_g][NKD k-steps over D], each k-step =
+// hi tile then lo tile, each tile lane-linear (16 B per lane).  The next chunk (NPC pieces per wave, +2 if `extra`)
+// is streamed from inside the X segment.
+template <int NKG, int NKH, int NKD, bool X3, bool PEND, int NPC, class WalkerT>
+__device__ __forceinline__ void tile_mma(WalkerT& wk, int lane, bool use_g, bool extra, const h8* Ghi, const h8* Glo, const h8* Xhi,
+                                         const h8* Xlo, const h8* Dhi, const h8* Dlo, Pend& cur, const Pend& prev, float inv_scale,
                                          float lower, h8& y0h, h8& y0l, h8& y1h, h8& y1l) {
-    const float4* bp = reinterpret_cast<const float4*>(chunk);
+    const char* chunk = wk.advance();
+    if (NPC > 0) wk.begin(NPC + (extra ? 2 : 0));
+    const float4* bp = reinterpret_cast<const float4*>(wk.bias_tab + wk.chunk * 32);
     const int h = lane >> 5;
 #pragma unroll
     for (int g = 0; g < 4; ++g) cur.bias[g] = bp[2 * g + h];
-    // the 4 bias reads and the fragment reads of the first two k-steps go first
-    __builtin_amdgcn_sched_group_barrier(0x100, 4 + (X3 ? 2 : 1) * (NKH < 2 ? NKH : 2), 0);
-    const char* p = chunk + kTileBytes + lane * 16;
-    ksteps<NKH, X3, PEND, true, true>(wk, p, Xhi, Xlo, cur.a1, cur.a2, prev, lower, y0h, y0l, y1h, y1l);
+    // the 4 bias reads and the fragment reads of the first three k-steps go first
+    __builtin_amdgcn_sched_group_barrier(0x100, 4 + (X3 ? 2 : 1) * (NKH < 3 ? NKH : 3), 0);
+    const char* p = chunk + lane * 16;
+    ksteps<NKH, X3, PEND, true, NPC>(wk, p, Xhi, Xlo, cur.a, prev, inv_scale, lower, extra, y0h, y0l, y1h, y1l);
     p += NKH * 2 * kTileBytes;
     if (NKG > 0) {
         if (use_g) {
             h8 d0, d1, d2, d3;
-            ksteps<NKG, X3, false, false, false>(wk, p, Ghi, Glo, cur.a1, cur.a2, prev, lower, d0, d1, d2, d3);
+            ksteps<NKG, X3, false, false, 0>(wk, p, Ghi, Glo, cur.a, prev, inv_scale, lower, false, d0, d1, d2, d3);
         }
     }
     if (NKD > 0) {
         h8 d0, d1, d2, d3;
-        ksteps<NKD, X3, false, false, false>(wk, p, Dhi, Dlo, cur.a1, cur.a2, prev, lower, d0, d1, d2, d3);
+        ksteps<NKD, X3, false, false, 0>(wk, p, Dhi, Dlo, cur.a, prev, inv_scale, lower, false, d0, d1, d2, d3);
     }
 }
 
 // A full layer of NT tiles reading X (+ gamma k-steps) and writing Y.  Tile rt accumulates into P[rt&1] while the
 // epilogue of the tile before it runs: for rt = 0 that is the LAST tile of the previous layer (in P1, destined for
 // k-steps 2*NT-2, 2*NT-1 of X itself), for rt > 0 tile rt-1 of this layer (destined for Y).  On return P1 holds
-// this layer's last tile, still pending.
-template <int NT, int NKG, int NKH, bool X3, bool PEND0, class WalkerT>
-__device__ __forceinline__ void layer(WalkerT& wk, int lane, bool use_g, int tiles_this, int tiles_after, const h8* Ghi,
-                                      const h8* Glo, h8* Xhi, h8* Xlo, h8* Yhi, h8* Ylo, Pend& P0, Pend& P1, float lower_prev,
-                                      float lower) {
+// this layer's last tile, still pending.  The chunks of this layer have 2*NKH/4 pieces per wave (+2 with the gamma
+// k-steps, i.e. when use_g); the chunk after the layer's last has NPC_AFTER (+2 if `extra_after`).
+template <int NT, int NKG, int NKH, bool X3, bool PEND0, int NPC_AFTER, class WalkerT>
+__device__ __forceinline__ void layer(WalkerT& wk, int lane, bool use_g, bool extra_after, const h8* Ghi, const h8* Glo, h8* Xhi,
+                                      h8* Xlo, h8* Yhi, h8* Ylo, Pend& P0, Pend& P1, float inv_scale, float lower_prev, float lower) {
     static_assert(NT % 2 == 0, "tiles per layer must be even (accumulator ping-pong)");
+    constexpr int NPC_THIS = 2 * NKH / kWaves;
 #pragma unroll
     for (int rt = 0; rt < NT; ++rt) {
-        const char* chunk = wk.advance(rt + 1 < NT ? tiles_this : tiles_after);
         Pend& cur = (rt & 1) ? P1 : P0;
         Pend& prev = (rt & 1) ? P0 : P1;
         if (rt == 0) {
             if constexpr (PEND0) {
                 constexpr int L = 2 * NT - 2;   // the previous layer has as many tiles as X has k-step pairs
-                tile_mma<NKG, NKH, 0, X3, true>(wk, chunk, lane, use_g, Ghi, Glo, Xhi, Xlo, nullptr, nullptr, cur, prev, lower_prev,
-                                                Xhi[L], Xlo[L], Xhi[L + 1], Xlo[L + 1]);
+                tile_mma<NKG, NKH, 0, X3, true, NPC_THIS>(wk, lane, use_g, use_g, Ghi, Glo, Xhi, Xlo, nullptr, nullptr, cur, prev,
+                                                          inv_scale, lower_prev, Xhi[L], Xlo[L], Xhi[L + 1], Xlo[L + 1]);
             } else {
                 h8 d0, d1, d2, d3;
-                tile_mma<NKG, NKH, 0, X3, false>(wk, chunk, lane, use_g, Ghi, Glo, Xhi, Xlo, nullptr, nullptr, cur, prev, lower_prev,
-                                                 d0, d1, d2, d3);
+                tile_mma<NKG, NKH, 0, X3, false, NPC_THIS>(wk, lane, use_g, use_g, Ghi, Glo, Xhi, Xlo, nullptr, nullptr, cur, prev,
+                                                           inv_scale, lower_prev, d0, d1, d2, d3);
             }
+        } else if (rt + 1 < NT) {
+            tile_mma<NKG, NKH, 0, X3, true, NPC_THIS>(wk, lane, use_g, use_g, Ghi, Glo, Xhi, Xlo, nullptr, nullptr, cur, prev, inv_scale,
+                                                      lower, Yhi[2 * rt - 2], Ylo[2 * rt - 2], Yhi[2 * rt - 1], Ylo[2 * rt - 1]);
         } else {
-            tile_mma<NKG, NKH, 0, X3, true>(wk, chunk, lane, use_g, Ghi, Glo, Xhi, Xlo, nullptr, nullptr, cur, prev, lower,
-                                            Yhi[2 * rt - 2], Ylo[2 * rt - 2], Yhi[2 * rt - 1], Ylo[2 * rt - 1]);
+            tile_mma<NKG, NKH, 0, X3, true, NPC_AFTER>(wk, lane, use_g, extra_after, Ghi, Glo, Xhi, Xlo, nullptr, nullptr, cur, prev,
+                                                       inv_scale, lower, Yhi[2 * rt - 2], Ylo[2 * rt - 2], Yhi[2 * rt - 1], Ylo[2 * rt - 1]);
         }
     }
 }
@@ -289,7 +298,7 @@ __device__ __forceinline__ void encode(float vx, float vy, float vz, int h, h8* 
             const float v = vals[s * 8 + j];
             const _Float16 hh = (_Float16)v;
             Ehi[s][j] = hh;
-            Elo[s][j] = X3 ? (_Float16)((v - (float)hh) * kLoScale) : (_Float16)0.f;
+            Elo[s][j] = X3 ? (_Float16)(v - (float)hh) : (_Float16)0.f;
         }
     }
 }
@@ -297,83 +306,88 @@ __device__ __forceinline__ void encode(float vx, float vy, float vz, int h, h8* 
 // One MLP evaluation for the wave's 32 points.  nerf/models/nerf_model.py:45-83.
 // Trunk layers 1..D-1 and the feature layer run as (D/2) pairs A->B, B->A so that the two activation register
 // sets keep fixed names inside a rolled loop; every tile's epilogue is deferred into the next tile (see Pend).
+// On entry the first chunk of the stream (layer 0, tile 0) is in flight.
 template <int W, int D, int SKIP, bool X3, class WalkerT>
-__device__ __forceinline__ void mlp_eval(WalkerT& wk, int lane, h8* Ghi, h8* Glo, const h8* GDhi, const h8* GDlo, float& o_r,
-                                         float& o_g, float& o_b, float& o_s) {
-    using S = Shape<W>;
+__device__ __forceinline__ void mlp_eval(WalkerT& wk, int lane, float inv_scale, h8* Ghi, h8* Glo, const h8* GDhi, const h8* GDlo,
+                                         float& o_r, float& o_g, float& o_b, float& o_s) {
+    using S = Shape<W, D>;
     static_assert(D % 2 == 0, "trunk depth must be even");
     static_assert(SKIP < 0 || SKIP % 2 == 0, "skip layer index must be even");
     static_assert(S::NT % 2 == 0 && S::NTV % 2 == 0, "tile counts must be even");
     h8 Ahi[S::KH], Alo[S::KH], Bhi[S::KH], Blo[S::KH];
     Pend P0, P1;
     constexpr int NPAIR = D / 2;
-    constexpr int SKIP_PAIR = SKIP < 0 ? -1 : SKIP / 2;   // pair whose first layer takes [gamma, h]
-    auto first_tiles = [&](int pair) { return pair == SKIP_PAIR ? S::T_S : S::T_H; };
+    constexpr int SKIP_PAIR = SKIP < 0 ? -1 : SKIP / 2;   // pair whose first layer takes [h, gamma]
 
-    // layer 0: gamma(x) -> A (nothing pending in front of its first tile)
-    layer<S::NT, 0, S::KG, X3, false>(wk, lane, false, S::T_L0, first_tiles(0), nullptr, nullptr, Ghi, Glo, Ahi, Alo, P0, P1, 0.f, 0.f);
-
+    // layer 0: gamma(x) -> A (nothing pending in front of its first tile); the chunk after it opens pair 0
+    layer<S::NT, 0, S::KG, X3, false, S::N_H>(wk, lane, false, SKIP_PAIR == 0, nullptr, nullptr, Ghi, Glo, Ahi, Alo, P0, P1, inv_scale,
+                                              0.f, 0.f);
 #pragma unroll 1
     for (int pair = 0; pair < NPAIR; ++pair) {
         const bool use_g = pair == SKIP_PAIR;
         const bool last = pair == NPAIR - 1;
         // first of pair: A (+gamma) -> B, ReLU.  Its first tile finishes the pending last tile of A (ReLU: the
         // producer is layer 0 or a non-final second-of-pair layer).
-        layer<S::NT, S::KG, S::KH, X3, true>(wk, lane, use_g, first_tiles(pair), S::T_H, Ghi, Glo, Ahi, Alo, Bhi, Blo, P0, P1, 0.f, 0.f);
-        // second of pair: B -> A; the last pair's second layer is _feature_linear (no ReLU, nerf_model.py:64)
-        const int after = last ? S::T_H /* alpha tile */ : first_tiles(pair + 1);
-        layer<S::NT, 0, S::KH, X3, true>(wk, lane, false, S::T_H, after, nullptr, nullptr, Bhi, Blo, Ahi, Alo, P0, P1, 0.f,
-                                         last ? -INFINITY : 0.f);
+        layer<S::NT, S::KG, S::KH, X3, true, S::N_H>(wk, lane, use_g, false, Ghi, Glo, Ahi, Alo, Bhi, Blo, P0, P1, inv_scale, 0.f, 0.f);
+        // second of pair: B -> A; the last pair's second layer is _feature_linear (no ReLU, nerf_model.py:64);
+        // after it comes the next pair's first layer (skip: 2 more pieces) or the alpha tile
+        layer<S::NT, 0, S::KH, X3, true, S::N_H>(wk, lane, false, !last && pair + 1 == SKIP_PAIR, nullptr, nullptr, Bhi, Blo, Ahi, Alo,
+                                                 P0, P1, inv_scale, 0.f, last ? -INFINITY : 0.f);
     }
     constexpr int L = 2 * S::NT - 2;
     // _alpha_linear on B, the input of _feature_linear (nerf_model.py:63); meanwhile the last feature tile (P1) is
     // finished into A without ReLU.  Rows 0 and 4 of the alpha tile both hold the single output row.
-    {
-        const char* chunk = wk.advance(S::T_V);
-        tile_mma<0, S::KH, 0, X3, true>(wk, chunk, lane, false, nullptr, nullptr, Bhi, Blo, nullptr, nullptr, P0, P1, -INFINITY,
-                                        Ahi[L], Alo[L], Ahi[L + 1], Alo[L + 1]);
-    }
-    const float sigma = pend_value(P0, 0, X3);
+    tile_mma<0, S::KH, 0, X3, true, S::N_V>(wk, lane, false, false, nullptr, nullptr, Bhi, Blo, nullptr, nullptr, P0, P1, inv_scale,
+                                            -INFINITY, Ahi[L], Alo[L], Ahi[L + 1], Alo[L + 1]);
+    const float sigma = pend_value(P0, 0, inv_scale);
     // view layer: [feature (A), gamma(d)] -> B[0..KV), ReLU (nerf_model.py:66-70); tile rt accumulates in P[(rt+1)&1]
 #pragma unroll
     for (int rt = 0; rt < S::NTV; ++rt) {
-        const char* chunk = wk.advance(rt + 1 < S::NTV ? S::T_V : S::T_RGB);
         Pend& cur = (rt & 1) ? P0 : P1;
         Pend& prev = (rt & 1) ? P1 : P0;
         if (rt == 0) {
             h8 d0, d1, d2, d3;   // the alpha tile (P0) has no activation output
-            tile_mma<0, S::KH, S::KD, X3, false>(wk, chunk, lane, false, nullptr, nullptr, Ahi, Alo, GDhi, GDlo, cur, prev, 0.f, d0, d1, d2, d3);
+            tile_mma<0, S::KH, S::KD, X3, false, S::N_V>(wk, lane, false, false, nullptr, nullptr, Ahi, Alo, GDhi, GDlo, cur, prev,
+                                                         inv_scale, 0.f, d0, d1, d2, d3);
+        } else if (rt + 1 < S::NTV) {
+            tile_mma<0, S::KH, S::KD, X3, true, S::N_V>(wk, lane, false, false, nullptr, nullptr, Ahi, Alo, GDhi, GDlo, cur, prev,
+                                                        inv_scale, 0.f, Bhi[2 * rt - 2], Blo[2 * rt - 2], Bhi[2 * rt - 1], Blo[2 * rt - 1]);
         } else {
-            tile_mma<0, S::KH, S::KD, X3, true>(wk, chunk, lane, false, nullptr, nullptr, Ahi, Alo, GDhi, GDlo, cur, prev, 0.f,
-                                                Bhi[2 * rt - 2], Blo[2 * rt - 2], Bhi[2 * rt - 1], Blo[2 * rt - 1]);
+            tile_mma<0, S::KH, S::KD, X3, true, S::N_RGB>(wk, lane, false, false, nullptr, nullptr, Ahi, Alo, GDhi, GDlo, cur, prev,
+                                                          inv_scale, 0.f, Bhi[2 * rt - 2], Blo[2 * rt - 2], Bhi[2 * rt - 1], Blo[2 * rt - 1]);
         }
     }
     // rgb head (nerf_model.py:74) in P1 while the last view tile (P0, NTV even) is finished into B; rows 0..2 and
-    // their copies 4..6 for the upper lane half
+    // their copies 4..6 for the upper lane half.  Nothing is streamed behind it: the caller starts the next pass.
     {
         constexpr int LV = 2 * S::NTV - 2;
-        const char* chunk = wk.advance(0);
-        tile_mma<0, S::KV, 0, X3, true>(wk, chunk, lane, false, nullptr, nullptr, Bhi, Blo, nullptr, nullptr, P1, P0, 0.f, Bhi[LV], Blo[LV],
-                                        Bhi[LV + 1], Blo[LV + 1]);
+        tile_mma<0, S::KV, 0, X3, true, 0>(wk, lane, false, false, nullptr, nullptr, Bhi, Blo, nullptr, nullptr, P1, P0, inv_scale, 0.f,
+                                           Bhi[LV], Blo[LV], Bhi[LV + 1], Blo[LV + 1]);
     }
-    o_r = pend_value(P1, 0, X3);
-    o_g = pend_value(P1, 1, X3);
-    o_b = pend_value(P1, 2, X3);
+    o_r = pend_value(P1, 0, inv_scale);
+    o_g = pend_value(P1, 1, inv_scale);
+    o_b = pend_value(P1, 2, inv_scale);
     o_s = sigma;
 }
 
-template <int W>
+constexpr int kMfmaMaxSamples = 64;   // coarse samples the per-wave LDS weight buffer is sized for
+
+template <int W, int D>
 struct Smem {
-    static constexpr int CHUNKS = 2 * Shape<W>::CHUNK_BYTES;
-    static constexpr int WOFF = CHUNKS;                                          // per-wave coarse weights / cdf
-    static constexpr int TOFF = WOFF + kWaves * kMaxSamples * kRaysPerWave * 4;  // t, 1-t, u tables
-    static constexpr int TOTAL = TOFF + (2 * kMaxSamples + kMaxImportance) * 4;
+    using S = Shape<W, D>;
+    static constexpr int CHUNKS = 2 * S::CHUNK_BYTES;
+    static constexpr int BOFF = CHUNKS;                                              // bias tables, coarse then fine
+    static constexpr int BIAS_BYTES = ((S::N_CHUNKS * 32 * 4 + 255) / 256) * 256;
+    static constexpr int WOFF = BOFF + 2 * BIAS_BYTES;                               // per-wave coarse weights / cdf
+    static constexpr int TOFF = WOFF + kWaves * kMfmaMaxSamples * kRaysPerWave * 4;  // t, 1-t, u tables
+    static constexpr int TOTAL = TOFF + (2 * kMfmaMaxSamples + kMaxImportance) * 4;
+    static_assert(TOTAL <= 160 * 1024, "LDS budget");
 };
 
 template <int W, int D, int SKIP, bool X3>
 __global__ void __launch_bounds__(256) render_mfma_kernel(RenderArgs a, NetMfma nc, NetMfma nf) {
-    using S = Shape<W>;
-    using SM = Smem<W>;
+    using S = Shape<W, D>;
+    using SM = Smem<W, D>;
     __shared__ __attribute__((aligned(16))) char smem[SM::TOTAL];
 
     const int lane = threadIdx.x & 63;
@@ -382,10 +396,15 @@ __global__ void __launch_bounds__(256) render_mfma_kernel(RenderArgs a, NetMfma 
     const int ns = a.n_samples, ni = a.n_importance;
 
     float* s_t = reinterpret_cast<float*>(smem + SM::TOFF);
-    float* s_omt = s_t + kMaxSamples;
-    float* s_u = s_omt + kMaxSamples;
+    float* s_omt = s_t + kMfmaMaxSamples;
+    float* s_u = s_omt + kMfmaMaxSamples;
     for (int i = threadIdx.x; i < ns; i += 256) { s_t[i] = a.t_vals[i]; s_omt[i] = a.omt_vals[i]; }
     for (int i = threadIdx.x; i < ni; i += 256) s_u[i] = a.u_vals[i];
+    float* s_bias = reinterpret_cast<float*>(smem + SM::BOFF);
+    for (int i = threadIdx.x; i < S::N_CHUNKS * 32; i += 256) {
+        s_bias[i] = nc.bias[i];
+        if (ni > 0) s_bias[SM::BIAS_BYTES / 4 + i] = nf.bias[i];
+    }
 
     const int64_t ridx = ((int64_t)blockIdx.x * kWaves + wave) * kRaysPerWave + (lane & 31);
     const bool live = ridx < a.n_rays && half == 0;
@@ -393,14 +412,15 @@ __global__ void __launch_bounds__(256) render_mfma_kernel(RenderArgs a, NetMfma 
     const Ray ray = load_ray(a, rclamp);
 
     Walker<S::CHUNK_BYTES> wk;
-    wk.buf0 = smem; wk.parity = 0; wk.wave = wave; wk.lane = lane; wk.dbg = a.dbg;
+    wk.buf0 = smem; wk.lds_chunks = (uint32_t)(uintptr_t)(LDS_AS char*)smem;
+    wk.parity = 0; wk.wave = wave; wk.lane_off = lane * 16; wk.dbg = a.dbg;
 
     // gamma(d): once per ray (model_utils.py:23-25 re-embeds the same direction for every sample)
     h8 GDhi[S::KD], GDlo[S::KD];
     encode<2, S::KD, X3>(ray.vx, ray.vy, ray.vz, half, GDhi, GDlo);
 
     FineSampler fs;
-    fs.wc = reinterpret_cast<float*>(smem + SM::WOFF) + wave * (kMaxSamples * kRaysPerWave) + (lane & 31);
+    fs.wc = reinterpret_cast<float*>(smem + SM::WOFF) + wave * (kMfmaMaxSamples * kRaysPerWave) + (lane & 31);
     fs.stride = kRaysPerWave; fs.t_tab = s_t; fs.omt_tab = s_omt; fs.u_tab = s_u; fs.ns = ns; fs.ni = ni;
     __syncthreads();
 
@@ -408,6 +428,7 @@ __global__ void __launch_bounds__(256) render_mfma_kernel(RenderArgs a, NetMfma 
     uint32_t flags = 0;
     for (int pass = 0; pass < (ni > 0 ? 2 : 1); ++pass) {
         const NetMfma& net = pass == 0 ? nc : nf;
+        const float* bias = s_bias + (pass == 0 ? 0 : SM::BIAS_BYTES / 4);
         const int Stot = pass == 0 ? ns : ns + ni;
         comp.reset();
         float z_cur, z_next = 0.f;
@@ -417,9 +438,10 @@ __global__ void __launch_bounds__(256) render_mfma_kernel(RenderArgs a, NetMfma 
             z_cur = a.z_fine_in ? a.z_fine_in[rclamp * Stot] : fs.next(ray);
         }
         for (int s = 0; s < Stot; ++s) {
-            wk.start(net.stream);
-            wk.begin(S::T_L0);   // first chunk of this evaluation flies while gamma(x) is computed
-            wk.issue_rest();
+            wk.start(net.stream, bias);
+            wk.begin(S::N_L0);   // first chunk of this evaluation flies while gamma(x) is computed
+#pragma unroll
+            for (int i = 0; i < S::N_L0; ++i) wk.piece(i);
             if (s + 1 < Stot) {
                 if (pass == 0) z_next = coarse_z(ray, s_t[s + 1], s_omt[s + 1]);
                 else z_next = a.z_fine_in ? a.z_fine_in[rclamp * Stot + s + 1] : fs.next(ray);
@@ -430,7 +452,7 @@ __global__ void __launch_bounds__(256) render_mfma_kernel(RenderArgs a, NetMfma 
             // handler.py:93: scalar_factor = 10, a true division (embedding.py:48)
             encode<5, S::KG, X3>(__fdiv_rn(px, 10.f), __fdiv_rn(py, 10.f), __fdiv_rn(pz, 10.f), half, Ghi, Glo);
             float rr, rg, rb, rs;
-            mlp_eval<W, D, SKIP, X3>(wk, lane, Ghi, Glo, GDhi, GDlo, rr, rg, rb, rs);
+            mlp_eval<W, D, SKIP, X3>(wk, lane, net.inv_scale, Ghi, Glo, GDhi, GDlo, rr, rg, rb, rs);
             const float w = comp.step(rr, rg, rb, rs, z_cur, z_next, s + 1 == Stot, ray.dnorm);
             if (pass == 0) fs.wc[s * kRaysPerWave] = w;
             if (live) {
@@ -462,6 +484,8 @@ bool mfma_supported(int D, int W, int in_xyz, int in_dir, int skip) {
     return (D == 8 && W == 256 && skip == 4) || (D == 4 && W == 128 && skip == -1);
 }
 
+int mfma_max_samples() { return kMfmaMaxSamples; }
+
 template <int W, int D, int SKIP>
 static void launch_t(const RenderArgs& a, const NetMfma& nc, const NetMfma& nf, bool three_pass, hipStream_t stream) {
     const int64_t rays_per_block = kWaves * kRaysPerWave;
@@ -473,10 +497,10 @@ static void launch_t(const RenderArgs& a, const NetMfma& nc, const NetMfma& nf, 
 }
 
 bool launch_render_mfma(const RenderArgs& a, const NetMfma& nc, const NetMfma& nf, bool three_pass, hipStream_t stream) {
-    const NetMfma& any = nc;
     if (a.n_importance > 0 && (nf.D != nc.D || nf.W != nc.W || nf.skip != nc.skip)) return false;
-    if (any.D == 8 && any.W == 256 && any.skip == 4) launch_t<256, 8, 4>(a, nc, nf, three_pass, stream);
-    else if (any.D == 4 && any.W == 128 && any.skip == -1) launch_t<128, 4, -1>(a, nc, nf, three_pass, stream);
+    if (a.n_samples > kMfmaMaxSamples) return false;
+    if (nc.D == 8 && nc.W == 256 && nc.skip == 4) launch_t<256, 8, 4>(a, nc, nf, three_pass, stream);
+    else if (nc.D == 4 && nc.W == 128 && nc.skip == -1) launch_t<128, 4, -1>(a, nc, nf, three_pass, stream);
     else return false;
     return true;
 }

@@ -209,6 +209,16 @@ class Renderer:
                 raise RuntimeError("nwe_packed_copy failed")
         return buf
 
+    def packed_bias(self, which: int) -> np.ndarray:
+        n = int(self._lib.nwe_packed_bias_count(self._ctx, which))
+        buf = np.empty(n, dtype=np.float32)
+        if n and self._lib.nwe_packed_bias_copy(self._ctx, which, buf.ctypes.data, n) != _lib.NWE_OK:
+            raise RuntimeError("nwe_packed_bias_copy failed")
+        return buf.reshape(-1, 32)
+
+    def packed_scale(self, which: int) -> float:
+        return float(self._lib.nwe_packed_scale(self._ctx, which))
+
     def selftest(self):
         rep = (C.c_int32 * 8)()
         rc = self._lib.nwe_selftest(self._ctx, rep)

@@ -9,19 +9,21 @@ of the same assumptions is checked on the GPU by nwe_selftest().
 import numpy as np
 
 TILE = 1024
-LO = 2048.0
 
 
 def split(v):
     hi = v.astype(np.float16)
-    lo = ((v - hi.astype(np.float32)) * np.float32(LO)).astype(np.float16)
+    lo = (v - hi.astype(np.float32)).astype(np.float16)
     return hi, lo
 
 
 class Stream:
-    def __init__(self, buf: np.ndarray):
-        self.buf = buf
+    """The packed network: tile stream (hi, lo per k-step), per-chunk bias table, weight scale."""
+
+    def __init__(self, buf: np.ndarray, bias: np.ndarray, scale: float):
+        self.buf, self.bias_tab, self.scale = buf, bias, np.float32(scale)
         self.pos = 0
+        self.chunk = 0
 
     def tile_f16(self):
         t = self.buf[self.pos:self.pos + TILE].view(np.float16).reshape(64, 8)   # [lane, j]
@@ -29,8 +31,8 @@ class Stream:
         return t
 
     def bias(self):
-        b = self.buf[self.pos:self.pos + 128].view(np.float32).copy()
-        self.pos += TILE
+        b = self.bias_tab[self.chunk].copy()
+        self.chunk += 1
         return b
 
 
@@ -57,18 +59,17 @@ def mma_tile(st: Stream, segs, three_pass=True):
     Returns the [32, n] fp32 tile (row-major, i.e. already un-permuted from the D register map)."""
     bias = st.bias()
     n = segs[0][0].shape[-1]
-    acc1 = np.repeat(bias[:, None], n, axis=1).astype(np.float64)
-    acc2 = np.zeros((32, n), dtype=np.float64)
+    acc = np.zeros((32, n), dtype=np.float64)
     for xhi, xlo in segs:
         for s in range(xhi.shape[0]):
             a_hi = st.tile_f16().astype(np.float64).reshape(2, 32, 8)   # [h, i, j]
             a_lo = st.tile_f16().astype(np.float64).reshape(2, 32, 8)
             bh = xhi[s].astype(np.float64)                               # [h, j, n]
             bl = xlo[s].astype(np.float64)
-            acc1 += np.einsum("hij,hjn->in", a_hi, bh)
+            acc += np.einsum("hij,hjn->in", a_hi, bh)
             if three_pass:
-                acc2 += np.einsum("hij,hjn->in", a_lo, bh) + np.einsum("hij,hjn->in", a_hi, bl)
-    return (acc1 + acc2 / LO).astype(np.float32)
+                acc += np.einsum("hij,hjn->in", a_lo, bh) + np.einsum("hij,hjn->in", a_hi, bl)
+    return (acc.astype(np.float32) / st.scale + bias[:, None]).astype(np.float32)
 
 
 def tile_to_operand(tile, lower):
@@ -93,9 +94,9 @@ def layer(st, n_tiles, segs, lower, three_pass=True):
     return np.concatenate(his, 0), np.concatenate(los, 0)
 
 
-def mlp_eval(stream_bytes, pts, dirs, D, W, skip, three_pass=True):
+def mlp_eval(stream_bytes, bias_tab, scale, pts, dirs, D, W, skip, three_pass=True):
     """pts [n,3] (already divided by 10), dirs [n,3] -> raw [n,4] as the kernel would produce."""
-    st = Stream(stream_bytes)
+    st = Stream(stream_bytes, bias_tab, scale)
     G = encode(pts.T.astype(np.float32), 5, 4)
     GD = encode(dirs.T.astype(np.float32), 2, 2)
     NT = W // 32
@@ -116,4 +117,5 @@ def mlp_eval(stream_bytes, pts, dirs, D, W, skip, three_pass=True):
     t = mma_tile(st, [Bv], three_pass)
     assert np.array_equal(t[0:3], t[4:7]), "rgb tile rows 4..6 must copy rows 0..2"
     assert st.pos == len(stream_bytes), (st.pos, len(stream_bytes))
+    assert st.chunk == len(bias_tab), (st.chunk, len(bias_tab))
     return np.stack([t[0], t[1], t[2], sigma], axis=1)

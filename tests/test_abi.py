@@ -66,19 +66,22 @@ def test_flops_per_eval_match_baseline():
 
 
 def test_stream_layout_properties():
-    """Weight stream invariants the kernel relies on: tile-aligned, bias tile first, hi + lo*2^-11 == weight."""
+    """Weight stream invariants the kernel relies on: tile-aligned, (hi, lo) tile pairs, (hi + lo) / scale == weight,
+    a separate bias table with one 32-float row per chunk."""
     sd = nwe_amd.synthetic.make_state_dict(9, 4, 128)
     r = nwe_amd.Renderer(host_only=True)
     r.set_network(0, sd)
-    s = r.packed_stream(0)
-    assert s.size % 1024 == 0
-    bias0 = s[:128].view(np.float32)
-    assert np.array_equal(bias0, sd["_pts_linears.0.bias"][:32]) and not s[128:1024].any()
-    hi = s[1024:2048].view(np.float16).astype(np.float64)
-    lo = s[2048:3072].view(np.float16).astype(np.float64)
+    s, bias, scale = r.packed_stream(0), r.packed_bias(0), r.packed_scale(0)
+    assert s.size % 1024 == 0 and np.log2(scale) == int(np.log2(scale))
+    assert np.array_equal(bias[0], sd["_pts_linears.0.bias"][:32])
+    hi = s[0:1024].view(np.float16).astype(np.float64)
+    lo = s[1024:2048].view(np.float16).astype(np.float64)
     # lane 0 (row 0, half 0), element 0 of k-step 0 is gamma slot 0 = sin(2^0 x) = column 3 of the encoding
     w = sd["_pts_linears.0.weight"]
-    assert abs(hi[0] + lo[0] / 2048 - w[0, 3]) < 1e-7 * max(1, abs(w[0, 3]))
-    assert abs(hi[1] + lo[1] / 2048 - w[0, 6]) < 1e-7                       # slot 1 = cos(2^0 x) = column 6
-    rec = hi + lo / 2048
-    assert np.abs(rec).max() <= np.abs(w).max() * 1.0001
+    assert abs((hi[0] + lo[0]) / scale - w[0, 3]) < 1e-7 * max(1, abs(w[0, 3]))
+    assert abs((hi[1] + lo[1]) / scale - w[0, 6]) < 1e-7                      # slot 1 = cos(2^0 x) = column 6
+    assert np.abs(hi).max() < 2.0 ** 15                                        # scaled into fp16 range with headroom
+    nz = lo[lo != 0]
+    assert (np.abs(nz) >= 2.0 ** -14).mean() > 0.99                            # lo halves are fp16-normal
+    # head tiles: rows 4..7 repeat rows 0..3 so that both lane halves see the outputs
+    assert np.array_equal(bias[-1][:3], sd["_rgb_linear.bias"]) and np.array_equal(bias[-1][4:7], sd["_rgb_linear.bias"])
