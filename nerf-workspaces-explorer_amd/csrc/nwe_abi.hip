@@ -146,7 +146,7 @@ void pack_mfma(NetState& n, const float* const* w, const float* const* b) {
     };
     layer(0, W, n.in_xyz, W / 32, 0, {{1, 4, 0}});
     for (int i = 1; i < D; ++i) {
-        if (i == n.skip + 1) layer(i, W, W + n.in_xyz, W / 32, 0, {{0, KH, n.in_xyz}, {1, 4, 0}});   // cat([pts, h]) (nerf_model.py:59), h k-steps streamed first
+        if (i == n.skip + 1) layer(i, W, W + n.in_xyz, W / 32, 0, {{1, 4, 0}, {0, KH, n.in_xyz}});   // cat([pts, h]), nerf_model.py:59
         else layer(i, W, W, W / 32, 0, {{0, KH, 0}});
     }
     const int iv = D, ife = D + 1, ia = D + 2, irgb = D + 3;
@@ -236,6 +236,10 @@ int launch(nwe_ctx* ctx, RenderArgs& a, int precision, void* stream_) {
     a.t_vals = ctx->d_t; a.omt_vals = ctx->d_omt; a.u_vals = ctx->d_u;
     a.n_samples = ctx->ns; a.n_importance = ctx->ni;
     { const char* e = getenv("NWE_DEBUG"); a.dbg = e ? atoi(e) : 0; }
+    {   // diagnostic builds: NWE_STAMPS_PTR carries a device pointer (decimal) to per-wave cycle sums
+        const char* e = getenv("NWE_STAMPS_PTR");
+        a.stamps = e ? reinterpret_cast<unsigned long long*>(strtoull(e, nullptr, 10)) : nullptr;
+    }
     if (a.n_rays <= 0) return NWE_OK;
     HIPCHK(ctx, hipEventRecord(ctx->ev0, stream));
     if (precision == NWE_PREC_F32) {

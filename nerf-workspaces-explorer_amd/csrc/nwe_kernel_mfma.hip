@@ -97,9 +97,16 @@ __device__ __forceinline__ void mma3(const h8& a_hi, const h8& a_lo, const h8& x
 // LDS-DMA goes through inline asm: hipcc's waitcnt pass treats a builtin global_load_lds as an LDS store that may
 // alias every later ds_read of the same array and drains vmcnt(0) in front of the first one, which would serialise
 // the prefetch with the compute it is meant to hide behind.  The asm form is invisible to that pass; completion is
-// waited for by hand in advance() (s_waitcnt vmcnt(0) + barrier).  M0 carries the wave-uniform LDS destination and
+// waited for by hand in sync() (s_waitcnt vmcnt(0) + barrier).  M0 carries the wave-uniform LDS destination and
 // is compiler-reserved, so it is saved and restored inside the statement.  Wave w streams the w-th quarter of a
 // chunk (n consecutive 1-KiB pieces): source = scalar base + lane*16, so a piece costs scalar instructions only.
+//
+// Timeline (tile T consumes chunk T from buffer T&1; PD = fragment prefetch distance in k-steps):
+//   * ONE barrier per tile, PD k-steps before the tile's end.  Before it every wave waits for its own LDS reads
+//     (all reads of chunk T have been issued by then) and its own DMA pieces (chunk T+1, issued >= 7 k-steps
+//     earlier).  After it (a) chunk T+1 is visible, so the A fragments of tile T+1's first PD k-steps are read
+//     during the last PD k-steps of tile T and the matrix pipe does not drain at the tile boundary, and (b) buffer
+//     T&1 is free, so the DMA of chunk T+2 starts at once: its first PD pieces in tile T, the rest early in T+1.
 template <int CHUNK_BYTES>
 struct Walker {
     const uint8_t* stream;
@@ -108,162 +115,251 @@ struct Walker {
     const char* buf0;
     const float* bias_tab;   // LDS bias table of the current network, 32 floats per chunk
     int chunk;               // index of the chunk being consumed
-    int parity;              // buffer the next chunk is written to
+    int b;                   // buffer holding the chunk being consumed
     int wave, dbg;
     uint32_t lane_off;       // lane * 16
     const uint8_t* blk_src;  // this wave's quarter of the chunk being streamed (uniform)
     uint32_t blk_dst;
+#ifdef NWE_STAMPS
+    unsigned long long st_pre = 0, st_wait = 0, st_post = 0, st_t0 = 0;
+#endif
 
     __device__ __forceinline__ void start(const uint8_t* s, const float* bias) {
-        stream = s; bias_tab = bias; next_tile = 0; chunk = -1;
+        stream = s; bias_tab = bias; next_tile = 0; chunk = 0; b = 0;
     }
-    __device__ __forceinline__ void begin(int n_per_wave) {
+    __device__ __forceinline__ const char* cur() const { return buf0 + b * CHUNK_BYTES; }
+    __device__ __forceinline__ const char* next() const { return buf0 + (b ^ 1) * CHUNK_BYTES; }
+    __device__ __forceinline__ void begin(int n_per_wave, int buffer) {
         blk_src = stream + ((size_t)next_tile + (size_t)wave * n_per_wave) * kTileBytes;
-        blk_dst = lds_chunks + parity * CHUNK_BYTES + wave * n_per_wave * kTileBytes;
+        blk_dst = lds_chunks + buffer * CHUNK_BYTES + wave * n_per_wave * kTileBytes;
         next_tile += n_per_wave * kWaves;
-        parity ^= 1;
     }
+    // Piece i of the chunk being streamed.  Pieces go in groups of four: one scalar base per group, the 1-KiB step inside
+    // a group rides on the instruction offset, which advances the global source AND the LDS destination (nwe_selftest
+    // report[6]).  i is a compile-time constant at every call site.
     __device__ __forceinline__ void piece(int i) {
-        if (dbg & 1) return;
-        const uint8_t* src = blk_src + (size_t)i * kTileBytes;
-        const uint32_t dst = blk_dst + i * kTileBytes;
+#ifdef NWE_EXP_NODMA   // timing experiments only; a run-time test here would split every k-step into its own basic block
+        return;
+#endif
+        const uint8_t* src = blk_src + (size_t)(i >> 2) * (4 * kTileBytes);
+        const uint32_t dst = blk_dst + (i >> 2) * (4 * kTileBytes);
         uint32_t keep;
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep) : "v"(lane_off), "s"(src), "s"(dst) : "memory");
-    }
-    // Make the chunk streamed last visible to every wave and return it.
-    __device__ __forceinline__ const char* advance() {
-        if (!(dbg & 2)) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
+        switch (i & 3) {
+#define NWE_GLDS(OFF)                                                                                                         \
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 offset:" #OFF "\n\ts_mov_b32 m0, %0" \
+                 : "=&s"(keep) : "v"(lane_off), "s"(src), "s"(dst) : "memory")
+            case 0: NWE_GLDS(0); break;
+            case 1: NWE_GLDS(1024); break;
+            case 2: NWE_GLDS(2048); break;
+            default: NWE_GLDS(3072); break;
+#undef NWE_GLDS
         }
-        ++chunk;
-        return buf0 + (parity ^ 1) * CHUNK_BYTES;
     }
+    __device__ __forceinline__ void sync() {
+#ifdef NWE_EXP_NOSYNC
+        return;
+#endif
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    __device__ __forceinline__ void tile_done() { b ^= 1; ++chunk; }
 };
 
-// NK k-steps of one tile with the A fragments (hi, lo tile pairs at p, lane-linear) read PD k-steps ahead of their
-// MFMAs and, if PEND, the epilogue of the previous tile spread over the k-steps (pairs [8s/NK, 8(s+1)/NK) are
-// finished BEFORE the MFMAs of k-step s, so a pending tile that feeds this tile's last two k-steps is complete in
-// time).  FIRST: the accumulator starts from the literal zero of the first MFMA.  NPC > 0: this wave's NPC (+2 if
-// `extra`) pieces of the next chunk are issued spread over the k-steps.
-template <int NK, bool X3, bool PEND, bool FIRST, int NPC, class WalkerT>
-__device__ __forceinline__ void ksteps(WalkerT& wk, const char* p, const h8* Xhi, const h8* Xlo, f16v& acc, const Pend& prev,
-                                       float inv_scale, float lower, bool extra, h8& y0h, h8& y0l, h8& y1h, h8& y1l) {
-    constexpr int PD = 3;
-    h8 fh[PD + 1], fl[PD + 1];
-#pragma unroll
-    for (int s = 0; s < PD && s < NK; ++s) {
-        fh[s] = *reinterpret_cast<const h8*>(p + (2 * s) * kTileBytes);
-        if (X3) fl[s] = *reinterpret_cast<const h8*>(p + (2 * s + 1) * kTileBytes);
-    }
-#pragma unroll
-    for (int s = 0; s < NK; ++s) {
-        if (NPC > 0) {
-#pragma unroll
-            for (int i = (s * NPC + NK - 1) / NK; i < ((s + 1) * NPC + NK - 1) / NK; ++i) wk.piece(i);
-            if (s == NK - 1 && extra) { wk.piece(NPC); wk.piece(NPC + 1); }
-        }
-        if (s + PD < NK) {
-            fh[(s + PD) % (PD + 1)] = *reinterpret_cast<const h8*>(p + (2 * (s + PD)) * kTileBytes);
-            if (X3) fl[(s + PD) % (PD + 1)] = *reinterpret_cast<const h8*>(p + (2 * (s + PD) + 1) * kTileBytes);
-        }
-        if (PEND) {
-#pragma unroll
-            for (int q = (8 * s) / NK; q < (8 * (s + 1)) / NK; ++q) finish_pair<X3>(prev, q, inv_scale, lower, y0h, y0l, y1h, y1l);
-        }
-        if (FIRST && s == 0) {
-            f16v zero;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) zero[r] = 0.f;
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[0], Xhi[0], zero, 0, 0, 0);
-            if (X3) {
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fl[0], Xhi[0], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[0], Xlo[0], acc, 0, 0, 0);
-            }
-        } else {
-            mma3<X3>(fh[s % (PD + 1)], fl[s % (PD + 1)], Xhi[s], Xlo[s], acc);
-        }
-        // Pin the issue order of this k-step (LLVM SchedGroupMask: 0x100 DS read, 0x8 MFMA, 0x2 VALU): the fragment
-        // reads of k-step s+PD, then each MFMA followed by a few epilogue VALU ops that execute while the matrix pipe
-        // works.  Without this hipcc sinks the reads next to their use and clusters the epilogue.
-        if (s + PD < NK) __builtin_amdgcn_sched_group_barrier(0x100, X3 ? 2 : 1, 0);
-        constexpr int V = PEND ? ((NK >= 16) ? (X3 ? 2 : 6) : ((NK >= 8) ? (X3 ? 4 : 12) : 8)) : 0;
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        if (V) __builtin_amdgcn_sched_group_barrier(0x002, V, 0);
-        if (X3) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            if (V) __builtin_amdgcn_sched_group_barrier(0x002, V, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            if (V) __builtin_amdgcn_sched_group_barrier(0x002, V, 0);
-        }
-    }
-    // Keep the epilogue HERE: its results are only consumed by the next layer, so without a use at this point
-    // LLVM sinks the whole epilogue of every tile of a layer to the layer's end (and keeps all their accumulators
-    // alive), which is exactly the un-overlapped VALU block this structure is meant to remove.
-    if (PEND) asm volatile("" : "+v"(y0h), "+v"(y0l), "+v"(y1h), "+v"(y1l));
-}
+constexpr int PD = 3;   // A fragments are read PD k-steps ahead of their MFMAs
+struct Frags { h8 hi[PD + 1], lo[PD + 1]; };   // ring, slot = (k-step counter) mod (PD+1)
 
-// One 32-row tile.  Chunk = [NKH k-steps over X][NKG gamma k-steps if use_g][NKD k-steps over D], each k-step =
-// hi tile then lo tile, each tile lane-linear (16 B per lane).  The next chunk (NPC pieces per wave, +2 if `extra`)
-// is streamed from inside the X segment.
-template <int NKG, int NKH, int NKD, bool X3, bool PEND, int NPC, class WalkerT>
-__device__ __forceinline__ void tile_mma(WalkerT& wk, int lane, bool use_g, bool extra, const h8* Ghi, const h8* Glo, const h8* Xhi,
-                                         const h8* Xlo, const h8* Dhi, const h8* Dlo, Pend& cur, const Pend& prev, float inv_scale,
-                                         float lower, h8& y0h, h8& y0l, h8& y1h, h8& y1l) {
-    const char* chunk = wk.advance();
-    if (NPC > 0) wk.begin(NPC + (extra ? 2 : 0));
+// One 32-row tile = NKP optional "pre" k-steps (gamma(x) of the skip layer, taken if use_g) + NKH main k-steps over
+// X + NKD "post" k-steps (gamma(d) of the view layer).  Chunk layout in that order, (hi, lo) tile pair per k-step,
+// lane-linear.  On entry the fragment ring holds this tile's first PD k-steps in slots PHASE..PHASE+PD-1; on exit
+// it holds the next tile's.  The epilogue of the PREVIOUS tile (`prev` -> y*) is spread over the main k-steps: pairs
+// [8s/NKH, 8(s+1)/NKH) are finished before the MFMAs of k-step s, so a pending tile that feeds this tile's last two
+// k-steps is ready in time.  DMA: this tile issues the pieces [PD, NB) (+2 if extraB) of chunk T+1 before its
+// barrier and, after it, pieces [0, min(PD, NA)) of chunk T+2 (NA pieces per wave, +2 if extraA; NA = 0: none).
+// HASNEXT: a tile follows in this pass (its first fragments are prefetched).
+template <int NKP, int NKH, int NKD, int PHASE, bool X3, bool PEND, int NB, int NA, bool HASNEXT, class WalkerT>
+__device__ __forceinline__ void tile_mma(WalkerT& wk, Frags& F, int lane, bool use_g, bool extraB, bool extraA, const h8* Ghi,
+                                         const h8* Glo, const h8* Xhi, const h8* Xlo, const h8* Dhi, const h8* Dlo, Pend& cur,
+                                         const Pend& prev, float inv_scale, float lower, h8& y0h, h8& y0l, h8& y1h, h8& y1l, int na_override = -1) {
+    constexpr int R = PD + 1;
+    constexpr int NQ = NKH + NKD;            // k-steps after the optional pre segment
+    constexpr int QSYNC = NQ - PD;           // the barrier sits in front of this k-step
+    static_assert(QSYNC >= 0, "tile too short for the prefetch distance");
+    static_assert(NKP % R == 0, "the optional segment must not shift the fragment ring");
     const float4* bp = reinterpret_cast<const float4*>(wk.bias_tab + wk.chunk * 32);
     const int h = lane >> 5;
 #pragma unroll
     for (int g = 0; g < 4; ++g) cur.bias[g] = bp[2 * g + h];
-    // the 4 bias reads and the fragment reads of the first three k-steps go first
-    __builtin_amdgcn_sched_group_barrier(0x100, 4 + (X3 ? 2 : 1) * (NKH < 3 ? NKH : 3), 0);
-    const char* p = chunk + lane * 16;
-    ksteps<NKH, X3, PEND, true, NPC>(wk, p, Xhi, Xlo, cur.a, prev, inv_scale, lower, extra, y0h, y0l, y1h, y1l);
-    p += NKH * 2 * kTileBytes;
-    if (NKG > 0) {
-        if (use_g) {
-            h8 d0, d1, d2, d3;
-            ksteps<NKG, X3, false, false, 0>(wk, p, Ghi, Glo, cur.a, prev, inv_scale, lower, false, d0, d1, d2, d3);
+    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+    const char* cbase = wk.cur() + lane * 16;
+    const char* nbase = wk.next() + lane * 16;
+    bool pre_done = false;
+    if (NKP > 0) {
+        if (use_g) {   // pre segment: positions 0..NKP-1 of the chunk; reads stay inside this chunk
+#pragma unroll
+            for (int s = 0; s < NKP; ++s) {
+                const int slot = (PHASE + s + PD) % R;
+                F.hi[slot] = *reinterpret_cast<const h8*>(cbase + (2 * (s + PD)) * kTileBytes);
+                if (X3) F.lo[slot] = *reinterpret_cast<const h8*>(cbase + (2 * (s + PD) + 1) * kTileBytes);
+                const int use = (PHASE + s) % R;
+                if (s == 0) {
+                    f16v zero;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) zero[r] = 0.f;
+                    cur.a = __builtin_amdgcn_mfma_f32_32x32x16_f16(F.hi[use], Ghi[0], zero, 0, 0, 0);
+                    if (X3) {
+                        cur.a = __builtin_amdgcn_mfma_f32_32x32x16_f16(F.lo[use], Ghi[0], cur.a, 0, 0, 0);
+                        cur.a = __builtin_amdgcn_mfma_f32_32x32x16_f16(F.hi[use], Glo[0], cur.a, 0, 0, 0);
+                    }
+                } else {
+                    mma3<X3>(F.hi[use], F.lo[use], Ghi[s], Glo[s], cur.a);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x100, X3 ? 2 : 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, X3 ? 3 : 1, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            cbase += NKP * 2 * kTileBytes;
+            pre_done = true;
         }
     }
-    if (NKD > 0) {
-        h8 d0, d1, d2, d3;
-        ksteps<NKD, X3, false, false, 0>(wk, p, Dhi, Dlo, cur.a, prev, inv_scale, lower, false, d0, d1, d2, d3);
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const h8* Xh = q < NKH ? &Xhi[q] : &Dhi[q - NKH];
+        const h8* Xl = q < NKH ? &Xlo[q] : &Dlo[q - NKH];
+        if (q == QSYNC) {
+#ifdef NWE_STAMPS
+            { const unsigned long long t = __builtin_amdgcn_s_memtime(); wk.st_pre += t - wk.st_t0; wk.st_t0 = t; }
+#endif
+            wk.sync();
+#ifdef NWE_STAMPS
+            { const unsigned long long t = __builtin_amdgcn_s_memtime(); wk.st_wait += t - wk.st_t0; wk.st_t0 = t; }
+#endif
+            if (NA > 0) wk.begin(na_override >= 0 ? na_override : NA + (extraA ? 2 : 0), wk.b);
+        }
+        // DMA pieces: the rest of chunk T+1 before the barrier (spread over k-steps 0..QSYNC-1), the head of chunk T+2 after
+        if (q < QSYNC && NB > PD) {
+            constexpr int REST = NB - PD;
+            constexpr int SPAN = QSYNC > 0 ? QSYNC : 1;
+#pragma unroll
+            for (int i = (q * REST + SPAN - 1) / SPAN; i < ((q + 1) * REST + SPAN - 1) / SPAN; ++i) wk.piece(PD + i);
+            if (q == 0 && extraB) { wk.piece(NB); wk.piece(NB + 1); }
+        }
+        if (q >= QSYNC && NA > 0 && q - QSYNC < (NA < PD ? NA : PD)) wk.piece(q - QSYNC);
+        // fragment read of position q+PD: this chunk, or the next tile's first k-steps (visible since the barrier)
+#ifdef NWE_EXP_NOLDS
+        if (false) {
+#else
+        if (q + PD < NQ) {
+#endif
+            const int slot = (PHASE + q + PD) % R;
+            F.hi[slot] = *reinterpret_cast<const h8*>(cbase + (2 * (q + PD)) * kTileBytes);
+            if (X3) F.lo[slot] = *reinterpret_cast<const h8*>(cbase + (2 * (q + PD) + 1) * kTileBytes);
+#ifdef NWE_EXP_NOLDS
+        } else if (false) {
+#else
+        } else if (HASNEXT) {
+#endif
+            const int slot = (PHASE + q + PD) % R;
+            if (X3) F.lo[slot] = *reinterpret_cast<const h8*>(nbase + (2 * (q + PD - NQ) + 1) * kTileBytes);
+            F.hi[slot] = *reinterpret_cast<const h8*>(nbase + (2 * (q + PD - NQ)) * kTileBytes);
+        }
+#ifdef NWE_EXP_NOEPI
+        if (PEND && q == 0) asm volatile("" :: "a"(prev.a));   // keeps the previous tile's MFMAs alive without an epilogue
+#else
+        if (PEND && q < NKH) {
+#pragma unroll
+            for (int p = (8 * q) / NKH; p < (8 * (q + 1)) / NKH; ++p) finish_pair<X3>(prev, p, inv_scale, lower, y0h, y0l, y1h, y1l);
+        }
+#endif
+        const int use = (PHASE + q) % R;
+        if (q == 0) {
+            if (NKP > 0 && pre_done) {
+                mma3<X3>(F.hi[use], F.lo[use], *Xh, *Xl, cur.a);
+            } else {
+                f16v zero;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) zero[r] = 0.f;
+                cur.a = __builtin_amdgcn_mfma_f32_32x32x16_f16(F.hi[use], *Xh, zero, 0, 0, 0);
+                if (X3) {
+                    cur.a = __builtin_amdgcn_mfma_f32_32x32x16_f16(F.lo[use], *Xh, cur.a, 0, 0, 0);
+                    cur.a = __builtin_amdgcn_mfma_f32_32x32x16_f16(F.hi[use], *Xl, cur.a, 0, 0, 0);
+                }
+            }
+        } else {
+            mma3<X3>(F.hi[use], F.lo[use], *Xh, *Xl, cur.a);
+        }
+        // Pin the issue order of this k-step (LLVM SchedGroupMask: 0x100 DS read, 0x8 MFMA, 0x2 VALU): the fragment
+        // reads first, then each MFMA followed by a few epilogue VALU ops that execute while the matrix pipe works.
+        // Without this hipcc sinks the reads next to their use and clusters the epilogue.
+        if (q + PD < NQ || HASNEXT) __builtin_amdgcn_sched_group_barrier(0x100, X3 ? 2 : 1, 0);
+        constexpr int V = PEND ? ((NKH >= 16) ? (X3 ? 2 : 6) : ((NKH >= 8) ? (X3 ? 4 : 12) : 8)) : 0;
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        if (V && q < NKH) __builtin_amdgcn_sched_group_barrier(0x002, V, 0);
+        if (X3) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if (V && q < NKH) __builtin_amdgcn_sched_group_barrier(0x002, V, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if (V && q < NKH) __builtin_amdgcn_sched_group_barrier(0x002, V, 0);
+        }
+        // Hard fence between k-steps: without it the scheduler fills the "DS read" groups with whatever reads it likes
+        // and sinks the prefetch reads (issued PD k-steps early on purpose) down to their first use, so that every
+        // k-step waits a full LDS latency.
+        __builtin_amdgcn_sched_barrier(0);
     }
+    // Keep the epilogue HERE: its results are only consumed by the next layer, so without a use at this point
+    // LLVM sinks the whole epilogue of every tile of a layer to the layer's end (and keeps all their accumulators
+    // alive), which is exactly the un-overlapped VALU block this structure is meant to remove.
+    // The "a" constraint also parks the finished fragments in the accumulator half of the register file, where the
+    // MFMAs read them directly; as plain VGPR values the allocator spills half of them there anyway and copies each
+    // back (4 v_accvgpr_read + s_nop) in front of every MFMA that uses it.
+    if (PEND) asm volatile("" : "+a"(y0h), "+a"(y0l), "+a"(y1h), "+a"(y1l));
+#ifdef NWE_STAMPS
+    { const unsigned long long t = __builtin_amdgcn_s_memtime(); wk.st_post += t - wk.st_t0; wk.st_t0 = t; }
+#endif
+    wk.tile_done();
 }
 
 // A full layer of NT tiles reading X (+ gamma k-steps) and writing Y.  Tile rt accumulates into P[rt&1] while the
 // epilogue of the tile before it runs: for rt = 0 that is the LAST tile of the previous layer (in P1, destined for
 // k-steps 2*NT-2, 2*NT-1 of X itself), for rt > 0 tile rt-1 of this layer (destined for Y).  On return P1 holds
-// this layer's last tile, still pending.  The chunks of this layer have 2*NKH/4 pieces per wave (+2 with the gamma
-// k-steps, i.e. when use_g); the chunk after the layer's last has NPC_AFTER (+2 if `extra_after`).
-template <int NT, int NKG, int NKH, bool X3, bool PEND0, int NPC_AFTER, class WalkerT>
-__device__ __forceinline__ void layer(WalkerT& wk, int lane, bool use_g, bool extra_after, const h8* Ghi, const h8* Glo, h8* Xhi,
-                                      h8* Xlo, h8* Yhi, h8* Ylo, Pend& P0, Pend& P1, float inv_scale, float lower_prev, float lower) {
-    static_assert(NT % 2 == 0, "tiles per layer must be even (accumulator ping-pong)");
-    constexpr int NPC_THIS = 2 * NKH / kWaves;
+// this layer's last tile, still pending.  Chunk sizes for the DMA schedule, in pieces per wave: this layer's chunks
+// N_THIS (+2 when use_g), the following layer's N_AFTER (+2 when extra_after), and `first_nb` = what tile 0 still
+// has to issue of chunk T+1 (0 at the very start of a pass, where chunks 0 and 1 are streamed up front).
+template <int NT, int NKP, int NKH, bool X3, bool PEND0, int N_AFTER, bool PASS_START, class WalkerT>
+__device__ __forceinline__ void layer(WalkerT& wk, Frags& F, int lane, bool use_g, bool extra_after, const h8* Ghi, const h8* Glo,
+                                      h8* Xhi, h8* Xlo, h8* Yhi, h8* Ylo, Pend& P0, Pend& P1, float inv_scale, float lower_prev,
+                                      float lower, int na_last_override = -1) {
+    static_assert(NT % 2 == 0 && NT >= 4, "tiles per layer must be even (accumulator ping-pong)");
+    constexpr int N_THIS = 2 * NKH / kWaves;
 #pragma unroll
     for (int rt = 0; rt < NT; ++rt) {
         Pend& cur = (rt & 1) ? P1 : P0;
         Pend& prev = (rt & 1) ? P0 : P1;
+        // chunk T+1 / T+2 seen from tile rt: inside the layer both are this layer's; at its end the next layer's
+        const bool ebB = rt + 1 < NT ? use_g : extra_after;
+        const bool ebA = rt + 2 < NT ? use_g : extra_after;
         if (rt == 0) {
+            constexpr int NB0 = PASS_START ? 0 : N_THIS;
             if constexpr (PEND0) {
                 constexpr int L = 2 * NT - 2;   // the previous layer has as many tiles as X has k-step pairs
-                tile_mma<NKG, NKH, 0, X3, true, NPC_THIS>(wk, lane, use_g, use_g, Ghi, Glo, Xhi, Xlo, nullptr, nullptr, cur, prev,
-                                                          inv_scale, lower_prev, Xhi[L], Xlo[L], Xhi[L + 1], Xlo[L + 1]);
+                tile_mma<NKP, NKH, 0, 0, X3, true, NB0, N_THIS, true>(wk, F, lane, use_g, ebB, ebA, Ghi, Glo, Xhi, Xlo, nullptr, nullptr,
+                                                                      cur, prev, inv_scale, lower_prev, Xhi[L], Xlo[L], Xhi[L + 1], Xlo[L + 1]);
             } else {
                 h8 d0, d1, d2, d3;
-                tile_mma<NKG, NKH, 0, X3, false, NPC_THIS>(wk, lane, use_g, use_g, Ghi, Glo, Xhi, Xlo, nullptr, nullptr, cur, prev,
-                                                           inv_scale, lower_prev, d0, d1, d2, d3);
+                tile_mma<NKP, NKH, 0, 0, X3, false, NB0, N_THIS, true>(wk, F, lane, use_g, ebB, ebA, Ghi, Glo, Xhi, Xlo, nullptr, nullptr,
+                                                                       cur, prev, inv_scale, lower_prev, d0, d1, d2, d3);
             }
+        } else if (rt + 2 < NT) {
+            tile_mma<NKP, NKH, 0, 0, X3, true, N_THIS, N_THIS, true>(wk, F, lane, use_g, ebB, ebA, Ghi, Glo, Xhi, Xlo, nullptr, nullptr, cur,
+                                                                     prev, inv_scale, lower, Yhi[2 * rt - 2], Ylo[2 * rt - 2], Yhi[2 * rt - 1],
+                                                                     Ylo[2 * rt - 1]);
         } else if (rt + 1 < NT) {
-            tile_mma<NKG, NKH, 0, X3, true, NPC_THIS>(wk, lane, use_g, use_g, Ghi, Glo, Xhi, Xlo, nullptr, nullptr, cur, prev, inv_scale,
-                                                      lower, Yhi[2 * rt - 2], Ylo[2 * rt - 2], Yhi[2 * rt - 1], Ylo[2 * rt - 1]);
+            tile_mma<NKP, NKH, 0, 0, X3, true, N_THIS, N_AFTER, true>(wk, F, lane, use_g, ebB, ebA, Ghi, Glo, Xhi, Xlo, nullptr, nullptr, cur,
+                                                                      prev, inv_scale, lower, Yhi[2 * rt - 2], Ylo[2 * rt - 2], Yhi[2 * rt - 1],
+                                                                      Ylo[2 * rt - 1]);
         } else {
-            tile_mma<NKG, NKH, 0, X3, true, NPC_AFTER>(wk, lane, use_g, extra_after, Ghi, Glo, Xhi, Xlo, nullptr, nullptr, cur, prev,
-                                                       inv_scale, lower, Yhi[2 * rt - 2], Ylo[2 * rt - 2], Yhi[2 * rt - 1], Ylo[2 * rt - 1]);
+            tile_mma<NKP, NKH, 0, 0, X3, true, N_AFTER, N_AFTER, true>(wk, F, lane, use_g, ebB, ebA, Ghi, Glo, Xhi, Xlo, nullptr, nullptr, cur,
+                                                                       prev, inv_scale, lower, Yhi[2 * rt - 2], Ylo[2 * rt - 2], Yhi[2 * rt - 1],
+                                                                       Ylo[2 * rt - 1], na_last_override);
         }
     }
 }
@@ -303,13 +399,37 @@ __device__ __forceinline__ void encode(float vx, float vy, float vz, int h, h8* 
     }
 }
 
+// View-layer tiles RT..NTV-1 (compile-time recursion: the DMA schedule and the ring phase depend on RT).  Tile RT
+// accumulates in P[(RT+1)&1]; tile 0 follows the alpha tile, which has no activation output to finish.  Each tile has
+// KH + KD k-steps, which shifts the fragment ring by (KH+KD) mod (PD+1) per tile.
+template <int RT, int W, int D, bool X3, class WalkerT>
+__device__ __forceinline__ void view_tiles(WalkerT& wk, Frags& F, int lane, const h8* Ahi, const h8* Alo, const h8* GDhi,
+                                           const h8* GDlo, h8* Bhi, h8* Blo, Pend& P0, Pend& P1, float inv_scale) {
+    using S = Shape<W, D>;
+    Pend& cur = (RT & 1) ? P0 : P1;
+    Pend& prev = (RT & 1) ? P1 : P0;
+    constexpr int PH = (RT * (S::KH + S::KD)) % (PD + 1);
+    constexpr int NB = RT + 1 < S::NTV ? S::N_V : S::N_RGB;                            // chunk T+1
+    constexpr int NA = RT + 2 < S::NTV ? S::N_V : (RT + 2 == S::NTV ? S::N_RGB : 0);   // chunk T+2
+    if constexpr (RT == 0) {
+        h8 d0, d1, d2, d3;
+        tile_mma<0, S::KH, S::KD, PH, X3, false, NB, NA, true>(wk, F, lane, false, false, false, nullptr, nullptr, Ahi, Alo, GDhi, GDlo, cur,
+                                                               prev, inv_scale, 0.f, d0, d1, d2, d3);
+    } else {
+        tile_mma<0, S::KH, S::KD, PH, X3, true, NB, NA, true>(wk, F, lane, false, false, false, nullptr, nullptr, Ahi, Alo, GDhi, GDlo, cur,
+                                                              prev, inv_scale, 0.f, Bhi[2 * RT - 2], Blo[2 * RT - 2], Bhi[2 * RT - 1],
+                                                              Blo[2 * RT - 1]);
+    }
+    if constexpr (RT + 1 < S::NTV) view_tiles<RT + 1, W, D, X3>(wk, F, lane, Ahi, Alo, GDhi, GDlo, Bhi, Blo, P0, P1, inv_scale);
+}
+
 // One MLP evaluation for the wave's 32 points.  nerf/models/nerf_model.py:45-83.
 // Trunk layers 1..D-1 and the feature layer run as (D/2) pairs A->B, B->A so that the two activation register
 // sets keep fixed names inside a rolled loop; every tile's epilogue is deferred into the next tile (see Pend).
-// On entry the first chunk of the stream (layer 0, tile 0) is in flight.
+// On entry chunks 0 and 1 of the stream are visible / in flight and F holds the first PD k-steps of chunk 0.
 template <int W, int D, int SKIP, bool X3, class WalkerT>
-__device__ __forceinline__ void mlp_eval(WalkerT& wk, int lane, float inv_scale, h8* Ghi, h8* Glo, const h8* GDhi, const h8* GDlo,
-                                         float& o_r, float& o_g, float& o_b, float& o_s) {
+__device__ __forceinline__ void mlp_eval(WalkerT& wk, Frags& F, int lane, float inv_scale, h8* Ghi, h8* Glo, const h8* GDhi,
+                                         const h8* GDlo, float& o_r, float& o_g, float& o_b, float& o_s) {
     using S = Shape<W, D>;
     static_assert(D % 2 == 0, "trunk depth must be even");
     static_assert(SKIP < 0 || SKIP % 2 == 0, "skip layer index must be even");
@@ -317,52 +437,40 @@ __device__ __forceinline__ void mlp_eval(WalkerT& wk, int lane, float inv_scale,
     h8 Ahi[S::KH], Alo[S::KH], Bhi[S::KH], Blo[S::KH];
     Pend P0, P1;
     constexpr int NPAIR = D / 2;
-    constexpr int SKIP_PAIR = SKIP < 0 ? -1 : SKIP / 2;   // pair whose first layer takes [h, gamma]
+    constexpr int SKIP_PAIR = SKIP < 0 ? -1 : SKIP / 2;   // pair whose first layer takes [gamma, h]
 
-    // layer 0: gamma(x) -> A (nothing pending in front of its first tile); the chunk after it opens pair 0
-    layer<S::NT, 0, S::KG, X3, false, S::N_H>(wk, lane, false, SKIP_PAIR == 0, nullptr, nullptr, Ghi, Glo, Ahi, Alo, P0, P1, inv_scale,
-                                              0.f, 0.f);
+    // layer 0: gamma(x) -> A (nothing pending in front of its first tile); the layer after it opens pair 0
+    layer<S::NT, 0, S::KG, X3, false, S::N_H, true>(wk, F, lane, false, SKIP_PAIR == 0, nullptr, nullptr, Ghi, Glo, Ahi, Alo, P0, P1,
+                                                    inv_scale, 0.f, 0.f);
 #pragma unroll 1
     for (int pair = 0; pair < NPAIR; ++pair) {
         const bool use_g = pair == SKIP_PAIR;
         const bool last = pair == NPAIR - 1;
-        // first of pair: A (+gamma) -> B, ReLU.  Its first tile finishes the pending last tile of A (ReLU: the
+        // first of pair: (gamma +) A -> B, ReLU.  Its first tile finishes the pending last tile of A (ReLU: the
         // producer is layer 0 or a non-final second-of-pair layer).
-        layer<S::NT, S::KG, S::KH, X3, true, S::N_H>(wk, lane, use_g, false, Ghi, Glo, Ahi, Alo, Bhi, Blo, P0, P1, inv_scale, 0.f, 0.f);
-        // second of pair: B -> A; the last pair's second layer is _feature_linear (no ReLU, nerf_model.py:64);
-        // after it comes the next pair's first layer (skip: 2 more pieces) or the alpha tile
-        layer<S::NT, 0, S::KH, X3, true, S::N_H>(wk, lane, false, !last && pair + 1 == SKIP_PAIR, nullptr, nullptr, Bhi, Blo, Ahi, Alo,
-                                                 P0, P1, inv_scale, 0.f, last ? -INFINITY : 0.f);
+        layer<S::NT, S::KG, S::KH, X3, true, S::N_H, false>(wk, F, lane, use_g, false, Ghi, Glo, Ahi, Alo, Bhi, Blo, P0, P1, inv_scale,
+                                                            0.f, 0.f);
+        // second of pair: B -> A; the last pair's second layer is _feature_linear (no ReLU, nerf_model.py:64).  After it
+        // comes the next pair's first layer (skip: 2 more pieces) or the alpha tile and then the view layer, whose
+        // chunk size the last feature tile needs for the head of chunk T+2.
+        layer<S::NT, 0, S::KH, X3, true, S::N_H, false>(wk, F, lane, false, !last && pair + 1 == SKIP_PAIR, nullptr, nullptr, Bhi, Blo,
+                                                        Ahi, Alo, P0, P1, inv_scale, 0.f, last ? -INFINITY : 0.f, last ? S::N_V : -1);
     }
     constexpr int L = 2 * S::NT - 2;
     // _alpha_linear on B, the input of _feature_linear (nerf_model.py:63); meanwhile the last feature tile (P1) is
     // finished into A without ReLU.  Rows 0 and 4 of the alpha tile both hold the single output row.
-    tile_mma<0, S::KH, 0, X3, true, S::N_V>(wk, lane, false, false, nullptr, nullptr, Bhi, Blo, nullptr, nullptr, P0, P1, inv_scale,
-                                            -INFINITY, Ahi[L], Alo[L], Ahi[L + 1], Alo[L + 1]);
+    tile_mma<0, S::KH, 0, 0, X3, true, S::N_V, S::N_V, true>(wk, F, lane, false, false, false, nullptr, nullptr, Bhi, Blo, nullptr, nullptr,
+                                                             P0, P1, inv_scale, -INFINITY, Ahi[L], Alo[L], Ahi[L + 1], Alo[L + 1]);
     const float sigma = pend_value(P0, 0, inv_scale);
-    // view layer: [feature (A), gamma(d)] -> B[0..KV), ReLU (nerf_model.py:66-70); tile rt accumulates in P[(rt+1)&1]
-#pragma unroll
-    for (int rt = 0; rt < S::NTV; ++rt) {
-        Pend& cur = (rt & 1) ? P0 : P1;
-        Pend& prev = (rt & 1) ? P1 : P0;
-        if (rt == 0) {
-            h8 d0, d1, d2, d3;   // the alpha tile (P0) has no activation output
-            tile_mma<0, S::KH, S::KD, X3, false, S::N_V>(wk, lane, false, false, nullptr, nullptr, Ahi, Alo, GDhi, GDlo, cur, prev,
-                                                         inv_scale, 0.f, d0, d1, d2, d3);
-        } else if (rt + 1 < S::NTV) {
-            tile_mma<0, S::KH, S::KD, X3, true, S::N_V>(wk, lane, false, false, nullptr, nullptr, Ahi, Alo, GDhi, GDlo, cur, prev,
-                                                        inv_scale, 0.f, Bhi[2 * rt - 2], Blo[2 * rt - 2], Bhi[2 * rt - 1], Blo[2 * rt - 1]);
-        } else {
-            tile_mma<0, S::KH, S::KD, X3, true, S::N_RGB>(wk, lane, false, false, nullptr, nullptr, Ahi, Alo, GDhi, GDlo, cur, prev,
-                                                          inv_scale, 0.f, Bhi[2 * rt - 2], Blo[2 * rt - 2], Bhi[2 * rt - 1], Blo[2 * rt - 1]);
-        }
-    }
+    // view layer: [feature (A), gamma(d)] -> B[0..KV), ReLU (nerf_model.py:66-70)
+    view_tiles<0, W, D, X3>(wk, F, lane, Ahi, Alo, GDhi, GDlo, Bhi, Blo, P0, P1, inv_scale);
     // rgb head (nerf_model.py:74) in P1 while the last view tile (P0, NTV even) is finished into B; rows 0..2 and
     // their copies 4..6 for the upper lane half.  Nothing is streamed behind it: the caller starts the next pass.
     {
         constexpr int LV = 2 * S::NTV - 2;
-        tile_mma<0, S::KV, 0, X3, true, 0>(wk, lane, false, false, nullptr, nullptr, Bhi, Blo, nullptr, nullptr, P1, P0, inv_scale, 0.f,
-                                           Bhi[LV], Blo[LV], Bhi[LV + 1], Blo[LV + 1]);
+        static_assert((S::NTV * (S::KH + S::KD)) % (PD + 1) == 0, "the view tiles must restore the ring phase");
+        tile_mma<0, S::KV, 0, 0, X3, true, 0, 0, false>(wk, F, lane, false, false, false, nullptr, nullptr, Bhi, Blo, nullptr, nullptr, P1,
+                                                        P0, inv_scale, 0.f, Bhi[LV], Blo[LV], Bhi[LV + 1], Blo[LV + 1]);
     }
     o_r = pend_value(P1, 0, inv_scale);
     o_g = pend_value(P1, 1, inv_scale);
@@ -413,7 +521,7 @@ __global__ void __launch_bounds__(256) render_mfma_kernel(RenderArgs a, NetMfma 
 
     Walker<S::CHUNK_BYTES> wk;
     wk.buf0 = smem; wk.lds_chunks = (uint32_t)(uintptr_t)(LDS_AS char*)smem;
-    wk.parity = 0; wk.wave = wave; wk.lane_off = lane * 16; wk.dbg = a.dbg;
+    wk.b = 0; wk.wave = wave; wk.lane_off = lane * 16; wk.dbg = a.dbg;
 
     // gamma(d): once per ray (model_utils.py:23-25 re-embeds the same direction for every sample)
     h8 GDhi[S::KD], GDlo[S::KD];
@@ -426,6 +534,10 @@ __global__ void __launch_bounds__(256) render_mfma_kernel(RenderArgs a, NetMfma 
 
     Composite comp;
     uint32_t flags = 0;
+#ifdef NWE_STAMPS
+    unsigned long long st_enc = 0, st_sync = 0, st_mlp = 0, st_comp = 0;
+    const unsigned long long st_begin = __builtin_amdgcn_s_memtime();
+#endif
     for (int pass = 0; pass < (ni > 0 ? 2 : 1); ++pass) {
         const NetMfma& net = pass == 0 ? nc : nf;
         const float* bias = s_bias + (pass == 0 ? 0 : SM::BIAS_BYTES / 4);
@@ -438,8 +550,15 @@ __global__ void __launch_bounds__(256) render_mfma_kernel(RenderArgs a, NetMfma 
             z_cur = a.z_fine_in ? a.z_fine_in[rclamp * Stot] : fs.next(ray);
         }
         for (int s = 0; s < Stot; ++s) {
+#ifdef NWE_STAMPS
+            const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+#endif
+            // chunks 0 and 1 (layer 0, tiles 0 and 1) fly while the sample's depth and gamma(x) are computed
             wk.start(net.stream, bias);
-            wk.begin(S::N_L0);   // first chunk of this evaluation flies while gamma(x) is computed
+            wk.begin(S::N_L0, 0);
+#pragma unroll
+            for (int i = 0; i < S::N_L0; ++i) wk.piece(i);
+            wk.begin(S::N_L0, 1);
 #pragma unroll
             for (int i = 0; i < S::N_L0; ++i) wk.piece(i);
             if (s + 1 < Stot) {
@@ -451,8 +570,25 @@ __global__ void __launch_bounds__(256) render_mfma_kernel(RenderArgs a, NetMfma 
             h8 Ghi[S::KG], Glo[S::KG];
             // handler.py:93: scalar_factor = 10, a true division (embedding.py:48)
             encode<5, S::KG, X3>(__fdiv_rn(px, 10.f), __fdiv_rn(py, 10.f), __fdiv_rn(pz, 10.f), half, Ghi, Glo);
+#ifdef NWE_STAMPS
+            const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+#endif
+            wk.sync();
+            Frags F;
+#pragma unroll
+            for (int k = 0; k < PD; ++k) {
+                F.hi[k] = *reinterpret_cast<const h8*>(wk.cur() + lane * 16 + (2 * k) * kTileBytes);
+                if (X3) F.lo[k] = *reinterpret_cast<const h8*>(wk.cur() + lane * 16 + (2 * k + 1) * kTileBytes);
+            }
+#ifdef NWE_STAMPS
+            const unsigned long long t2 = __builtin_amdgcn_s_memtime();
+            wk.st_t0 = t2;
+#endif
             float rr, rg, rb, rs;
-            mlp_eval<W, D, SKIP, X3>(wk, lane, net.inv_scale, Ghi, Glo, GDhi, GDlo, rr, rg, rb, rs);
+            mlp_eval<W, D, SKIP, X3>(wk, F, lane, net.inv_scale, Ghi, Glo, GDhi, GDlo, rr, rg, rb, rs);
+#ifdef NWE_STAMPS
+            const unsigned long long t3 = __builtin_amdgcn_s_memtime();
+#endif
             const float w = comp.step(rr, rg, rb, rs, z_cur, z_next, s + 1 == Stot, ray.dnorm);
             if (pass == 0) fs.wc[s * kRaysPerWave] = w;
             if (live) {
@@ -464,6 +600,10 @@ __global__ void __launch_bounds__(256) render_mfma_kernel(RenderArgs a, NetMfma 
                 if (pass == 1 && a.out.z_fine) a.out.z_fine[ridx * Stot + s] = z_cur;
             }
             z_cur = z_next;
+#ifdef NWE_STAMPS
+            const unsigned long long t4 = __builtin_amdgcn_s_memtime();
+            st_enc += t1 - t0; st_sync += t2 - t1; st_mlp += t3 - t2; st_comp += t4 - t3;
+#endif
         }
         if (live) {
             flags |= store_ray(a.out, ridx, comp, pass == 1);
@@ -477,6 +617,13 @@ __global__ void __launch_bounds__(256) render_mfma_kernel(RenderArgs a, NetMfma 
         }
     }
     if (flags && a.out.flags) atomicOr(a.out.flags, flags);
+#ifdef NWE_STAMPS
+    if (a.stamps && lane == 0) {   // diagnostic build only: a buffer no other code reads
+        unsigned long long* o = a.stamps + ((size_t)blockIdx.x * kWaves + wave) * 8;
+        o[0] = st_enc; o[1] = st_sync; o[2] = st_mlp; o[3] = st_comp; o[4] = __builtin_amdgcn_s_memtime() - st_begin;
+        o[5] = wk.st_pre; o[6] = wk.st_wait; o[7] = wk.st_post;
+    }
+#endif
 }
 
 bool mfma_supported(int D, int W, int in_xyz, int in_dir, int skip) {

@@ -7,6 +7,8 @@
 //   report[3]  mismatches of the LDS-DMA (global_load_lds_dwordx4) lane order: LDS[base + 16*lane]
 //   report[4]  max |sincosf - fp64| over arguments up to 1.1e3 rad, in units of 1e-9 (informational)
 //   report[5]  max relative error of expf over [-20, 20], in units of 1e-9 (informational)
+//   report[6]  mismatches of the scalar-base + immediate-offset LDS-DMA form the render kernel uses: the instruction
+//              offset must advance BOTH the global source and the LDS destination
 #include <cmath>
 #include <vector>
 
@@ -23,8 +25,10 @@ __host__ __device__ inline int tA2(int i, int f) { return ((i + 2 * f) % 5) - 2;
 __host__ __device__ inline int hidden_col_d(int s, int h, int j) { return 16 * s + 8 * (j >> 2) + 4 * h + (j & 3); }
 
 __global__ void selftest_kernel(float* d1 /*32x32*/, float* d2 /*32x32*/, float* sub, const uint32_t* pattern,
-                                uint32_t* lds_out /*2 x 256 words*/, const float* args, float* sc /*2n*/, float* ex, int n) {
+                                uint32_t* lds_out /*2 x 256 words*/, const float* args, float* sc /*2n*/, float* ex, int n,
+                                uint32_t* lds_out2 /*2 x 256 words*/) {
     __shared__ __attribute__((aligned(16))) uint32_t s_buf[512];
+    __shared__ __attribute__((aligned(16))) uint32_t s_buf2[512];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 31, h = lane >> 5;
     if (wave == 0) {
@@ -58,9 +62,17 @@ __global__ void selftest_kernel(float* d1 /*32x32*/, float* d2 /*32x32*/, float*
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                          (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
     }
+    // the render kernel's form: scalar 64-bit base, per-lane 32-bit offset, M0 = LDS base, immediate offset on both sides
+    if (wave == 2) {
+        const uint32_t lane_off = lane * 16;
+        const char* src = reinterpret_cast<const char*>(pattern);
+        const uint32_t dst = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)s_buf2;
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1\n\tglobal_load_lds_dwordx4 %0, %1 offset:1024"
+                     :: "v"(lane_off), "s"(src), "s"(dst) : "memory", "m0");
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    for (int k = threadIdx.x; k < 512; k += blockDim.x) lds_out[k] = s_buf[k];
+    for (int k = threadIdx.x; k < 512; k += blockDim.x) { lds_out[k] = s_buf[k]; lds_out2[k] = s_buf2[k]; }
     for (int k = threadIdx.x; k < n; k += blockDim.x) {
         float sn, cs;
         sincosf(args[k], &sn, &cs);
@@ -81,23 +93,24 @@ int run_selftest(int32_t* rep, hipStream_t stream) {
     }
     std::vector<uint32_t> pat(512);
     for (int k = 0; k < 512; ++k) pat[k] = 0x9e3779b9u * (k + 1);
-    float *d1, *d2, *sub, *dargs, *sc, *ex; uint32_t *dpat, *dlds;
+    float *d1, *d2, *sub, *dargs, *sc, *ex; uint32_t *dpat, *dlds, *dlds2;
     ST_CHK(hipMalloc(&d1, 4096)); ST_CHK(hipMalloc(&d2, 4096)); ST_CHK(hipMalloc(&sub, 16));
     ST_CHK(hipMalloc(&dargs, n * 4)); ST_CHK(hipMalloc(&sc, n * 8)); ST_CHK(hipMalloc(&ex, n * 4));
-    ST_CHK(hipMalloc(&dpat, 2048)); ST_CHK(hipMalloc(&dlds, 2048));
+    ST_CHK(hipMalloc(&dpat, 2048)); ST_CHK(hipMalloc(&dlds, 2048)); ST_CHK(hipMalloc(&dlds2, 2048));
     ST_CHK(hipMemcpy(dargs, args.data(), n * 4, hipMemcpyHostToDevice));
     ST_CHK(hipMemcpy(dpat, pat.data(), 2048, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(selftest_kernel, dim3(1), dim3(256), 0, stream, d1, d2, sub, dpat, dlds, dargs, sc, ex, n);
+    hipLaunchKernelGGL(selftest_kernel, dim3(1), dim3(256), 0, stream, d1, d2, sub, dpat, dlds, dargs, sc, ex, n, dlds2);
     ST_CHK(hipGetLastError());
     ST_CHK(hipStreamSynchronize(stream));
-    std::vector<float> h1(1024), h2(1024), hsc(2 * n), hex(n); float hsub = -1.f; std::vector<uint32_t> hl(512);
+    std::vector<float> h1(1024), h2(1024), hsc(2 * n), hex(n); float hsub = -1.f; std::vector<uint32_t> hl(512), hl2(512);
     ST_CHK(hipMemcpy(h1.data(), d1, 4096, hipMemcpyDeviceToHost));
     ST_CHK(hipMemcpy(h2.data(), d2, 4096, hipMemcpyDeviceToHost));
     ST_CHK(hipMemcpy(&hsub, sub, 4, hipMemcpyDeviceToHost));
     ST_CHK(hipMemcpy(hl.data(), dlds, 2048, hipMemcpyDeviceToHost));
+    ST_CHK(hipMemcpy(hl2.data(), dlds2, 2048, hipMemcpyDeviceToHost));
     ST_CHK(hipMemcpy(hsc.data(), sc, n * 8, hipMemcpyDeviceToHost));
     ST_CHK(hipMemcpy(hex.data(), ex, n * 4, hipMemcpyDeviceToHost));
-    for (void* p : {(void*)d1, (void*)d2, (void*)sub, (void*)dargs, (void*)sc, (void*)ex, (void*)dpat, (void*)dlds}) (void)hipFree(p);
+    for (void* p : {(void*)d1, (void*)d2, (void*)sub, (void*)dargs, (void*)sc, (void*)ex, (void*)dpat, (void*)dlds, (void*)dlds2}) (void)hipFree(p);
 
     std::vector<int> X(1024);
     for (int i = 0; i < 32; ++i)
@@ -115,6 +128,7 @@ int run_selftest(int32_t* rep, hipStream_t stream) {
         }
     rep[2] = hsub == 0.015625f ? 1 : (hsub == 0.f ? 0 : -1);
     for (int k = 0; k < 512; ++k) if (hl[k] != pat[k]) rep[3]++;
+    for (int k = 0; k < 512; ++k) if (hl2[k] != pat[k]) rep[6]++;
     double worst = 0.0, worst_e = 0.0;
     for (int k = 0; k < n; ++k) {
         worst = std::fmax(worst, std::fabs((double)hsc[2 * k] - std::sin((double)args[k])));
@@ -124,7 +138,7 @@ int run_selftest(int32_t* rep, hipStream_t stream) {
     }
     rep[4] = (int32_t)(worst * 1e9);
     rep[5] = (int32_t)(worst_e * 1e9);
-    return (rep[0] == 0 && rep[1] == 0 && rep[3] == 0) ? 0 : 1;
+    return (rep[0] == 0 && rep[1] == 0 && rep[3] == 0 && rep[6] == 0) ? 0 : 1;
 }
 
 }  // namespace nwe

@@ -106,7 +106,7 @@ def mlp_eval(stream_bytes, bias_tab, scale, pts, dirs, D, W, skip, three_pass=Tr
     sigma = None
     for pair in range(npair):
         last = pair == npair - 1
-        segs = [A] + ([G] if pair == skip_pair else [])       # hidden k-steps are streamed before the gamma ones
+        segs = ([G] if pair == skip_pair else []) + [A]
         B = layer(st, NT, segs, 0.0, three_pass)
         A = layer(st, NT, [B], -np.inf if last else 0.0, three_pass)
         if last:
