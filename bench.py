@@ -34,6 +34,9 @@ if ROOT not in sys.path:
 H = W = 800
 NS, NI = 64, 128
 PEAK_F16_TFLOPS = 2500.0   # dense fp16/bf16 MFMA peak, MI355X_MICROARCH.md
+# HBM-side bytes of one C3-frame launch from rocprofv3 PMC passes (profiles/r01_pmc_traffic.txt): 2 x FETCH_SIZE (gfx950
+# reports half of a 16-B-per-lane stream) + WRITE_SIZE; L2 misses of the 3.1 TB weight stream, not a bound (21 GB/s).
+TRAFFIC_BYTES_C3_LAUNCH = 2 * 4.87e6 * 1024 + 1.025e5 * 1024
 CPU_SAMPLE_RAYS = 8192     # one reference chunk (inference.chunk = 1024*8): ~10 s of CPU work on 8-16 cores
 
 
@@ -145,7 +148,10 @@ def main() -> None:
             "rays_per_s": rays_per_step * args.steps / elapsed,
             "mlp_evals_per_s": rays_per_step * evals_per_ray * args.steps / elapsed,
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_F16_TFLOPS, "traffic": None,
+                         "frac": achieved / PEAK_F16_TFLOPS,
+                         "traffic": TRAFFIC_BYTES_C3_LAUNCH if (world == 1 and args.precision == "f16x3") else None,
+                         "traffic_note": "HBM-side bytes per launch from separate rocprofv3 --pmc passes (profiles/r01_pmc_traffic.txt), "
+                                         "not measured in this run; algorithmic 1.76e7 B",
                          "kernel": "render_mfma_kernel<256,8,4>" if args.precision != "f32" else "render_f32_kernel",
                          "kernel_ms": k_ms, "algorithmic_flops_per_launch": flops_per_launch,
                          "executed_mfma_passes": passes, "frac_executed": achieved * passes / PEAK_F16_TFLOPS},

@@ -329,6 +329,60 @@ def test_c3_full_frame_mfma_against_fp32_kernel():
     r.close()
 
 
+def test_c2_coarse_only_400(r_c3):
+    """BASELINE config 2 geometry: 400x400, 64 coarse samples, 8x256, no importance pass.  The reference handler
+    raises UnboundLocalError with n_importance == 0 (handler.py:263); here the coarse result fills the output slots.
+    Checked against the live oracle on a strided subset of the frame, every ray."""
+    sd_c = _sd(1000, 8, 256)
+    r = nwe_amd.Renderer(0)
+    r.set_network(0, sd_c)
+    r.set_sampling(64, 0)
+    fx, fy, cx, cy = O.intrinsics(400, 400)
+    pose = O.camera_pose((0.0, -0.5, -0.75 / np.cos(-10 / 180 * np.pi), 0.0, -90.0, 0.0), (0, 0, 0, 0.0, 0.0, 0.0))
+    out = r.render(pose[0].numpy(), 400, 400, fx=fx, fy=fy, cx=cx, cy=cy, near=0.1, far=10.0, outputs=("rgb", "depth", "acc", "raw_coarse"))
+    assert out["rgb"].shape == (160000, 3)
+    idx = torch.arange(0, 160000, 157)
+    rays = O.create_rays(pose, 400, 400, fx, fy, cx, cy, 0.1, 10.0)[0][idx].contiguous()
+    ref = O.render_rays(rays, _t(sd_c), None, O.RenderConfig(n_samples=64, n_importance=0))
+    cliff = ref["raw_coarse"][:, -1, 3].abs().numpy() < 1e-5
+    err = np.abs(out["rgb"][idx.cuda()].cpu().numpy() - ref["rgb_coarse"].numpy())
+    print("C2 400x400 coarse-only: rgb max err", err[~cliff].max(), "cliff rays", int(cliff.sum()), "kernel ms", r.last_kernel_ms())
+    assert err[~cliff].max() <= RGB_TOL
+    assert np.abs(out["depth"][idx.cuda()].cpu().numpy() - ref["depth_coarse"].numpy())[~cliff].max() / FAR <= 1e-4
+    assert np.abs(out["raw_coarse"][idx.cuda()].cpu().numpy() - ref["raw_coarse"].numpy()).max() < 5e-5
+    r.close()
+
+
+def test_c5_pose_sweep_batch(r_c3):
+    """BASELINE config 5 in miniature: a GUI turn-left sweep (30 degree steps, application/app.py:198) rendered as ONE
+    batch launch and sharded into row tiles as the multi-GPU path does; tiles and batch must reassemble bit for bit."""
+    from nwe_amd.dist import shard_rows
+    fx, fy, cx, cy = O.intrinsics(32, 40)
+    init = nwe_amd.COORD(x=0.0, y=-0.5, z=-0.76, pitch=-90.0)
+    poses = nwe_amd.get_camera_poses_from_list_of_coordinates(init, [nwe_amd.COORD(yaw=-30.0 * k) for k in range(6)]).numpy()
+    kw = dict(fx=fx, fy=fy, cx=cx, cy=cy, near=0.1, far=10.0, outputs=("rgb", "depth", "acc"))
+    batch = r_c3.render(poses, 32, 40, **kw)
+    rgb = batch["rgb"].reshape(6, 32, 40, 3)
+    for k in (0, 3, 5):
+        one = r_c3.render(poses[k], 32, 40, **kw)
+        assert torch.equal(one["rgb"].reshape(32, 40, 3), rgb[k])
+    tiles = [r_c3.render(poses, 32, 40, rows=rr, **kw)["rgb"].reshape(6, rr[1] - rr[0], 40, 3) for rr in shard_rows(32, 3)]
+    assert torch.equal(torch.cat(tiles, dim=1), rgb)
+    assert (rgb[0] - rgb[3]).abs().max() > 1e-3          # the views differ
+
+
+def test_workspace_click_render():
+    """application/workspace.py:54-68 end to end: floor-plan click -> pose -> uint8 frame."""
+    ws = nwe_amd.Workspace("Office Geneve")
+    ws.initialize_models(state_dicts=(nwe_amd.synthetic.thin_fog(_sd(1000, 8, 256)), _sd(1001, 8, 256)))
+    a = ws.render_image(0.4, 0.6, 0, 0)
+    b = ws.render_image(0.4, 0.6, 30, 0)
+    assert a.shape == (240, 320, 3) and a.dtype == np.uint8 and a.flags["C_CONTIGUOUS"]
+    assert np.abs(a.astype(int) - b.astype(int)).max() > 0
+    init, loc = ws.transform_relative_coordinates(0.4, 0.6, 30, 0)
+    assert np.array_equal(ws.handler.render_coordinates(init, loc), b)
+
+
 def test_to8b_truncates(r_c1):
     x = torch.tensor([-0.5, 0.0, 0.5, 0.999, 1.0, 1.5, 254.9999 / 255.0, 1e-9, 100 / 255.0], device="cuda")
     got = r_c1.to8b(x).cpu().numpy()

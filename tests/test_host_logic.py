@@ -89,3 +89,31 @@ def test_synthetic_weights_are_deterministic():
     assert abs(float(a["_pts_linears.3.weight"].max()) - 2 / 16) < 1e-3
     fog = nwe_amd.synthetic.thin_fog(a)
     assert np.all(fog["_alpha_linear.bias"] == np.float32(0.08)) and np.array_equal(fog["_rgb_linear.weight"], a["_rgb_linear.weight"])
+
+
+def test_workspace_click_maps():
+    """The four office maps (application/workspace.py:71-196), pinned on hand-computed clicks."""
+    C = nwe_amd.click_to_coordinates
+    init, loc = C("Office Tokyo", 0.5, 0.5, 30, 0)          # SURVEY.md §8(d): centre click
+    c10 = np.cos(-10 / 180 * np.pi)
+    assert abs(init.x - 0.0 / c10) < 1e-12 and init.y == -0.5 and abs(init.z - (-0.75 / c10)) < 1e-12
+    assert (init.yaw, init.pitch, init.roll) == (0.0, -90.0, 0.0) and (loc.yaw, loc.pitch) == (-30.0, 0.0)
+    init, _ = C("Office Tokyo", 0.0, 1.0, 0, 0)             # x' from rel_y (-> x_min), z' from rel_x (-> z_max)
+    assert abs(init.x - (-2.0 / c10)) < 1e-12 and abs(init.z - (1.5 / c10)) < 1e-12
+    init, _ = C("Office New York", 0.0, 1.0, 0, 0)          # New York swaps: x' from rel_x (-> x_max), z' from rel_y (-> z_min)
+    c45 = np.cos(45 / 180 * np.pi)
+    assert abs(init.x - 1.8 / c45) < 1e-12 and abs(init.z - (-1.6 / c45)) < 1e-12
+    init, _ = C("Office Geneve", 1.0, 0.0, 0, 0)
+    c35 = np.cos(35 / 180 * np.pi)
+    assert abs(init.x - 1.7 / c35) < 1e-12 and abs(init.z - (-2.8 / c35)) < 1e-12
+    init, loc = C("Office Belgrade", 0.25, 0.75, -60, 30)
+    assert abs(init.x - ((-0.7 - 4.7) * 0.75 + 4.7) / c10) < 1e-12 and abs(init.z - ((-2.3 - 3.5) * 0.25 + 3.5) / c10) < 1e-12
+    assert (loc.yaw, loc.pitch) == (60.0, 30.0)
+    assert set(nwe_amd.OFFICES) == {"Office Tokyo", "Office New York", "Office Geneve", "Office Belgrade"}
+    assert nwe_amd.OFFICES["Office Geneve"].floor_plan_scale == nwe_amd.HW(600, 1000)
+    ws = nwe_amd.Workspace("Office New York")
+    assert ws.name == "Office New York" and repr(ws) == "Office New York" and ws.handler.image_size == (240, 320)
+    with pytest.raises(RuntimeError, match="cannot be found"):
+        ws.initialize_models()
+    with pytest.raises(KeyError):
+        nwe_amd.Workspace("Office Paris")
