@@ -171,9 +171,8 @@ struct Frags { h8 hi[PD + 1], lo[PD + 1]; };   // ring, slot = (k-step counter) 
 // One 32-row tile = NKP optional "pre" k-steps (gamma(x) of the skip layer, taken if use_g) + NKH main k-steps over
 // X + NKD "post" k-steps (gamma(d) of the view layer).  Chunk layout in that order, (hi, lo) tile pair per k-step,
 // lane-linear.  On entry the fragment ring holds this tile's first PD k-steps in slots PHASE..PHASE+PD-1; on exit
-// it holds the next tile's.  The epilogue of the PREVIOUS tile (`prev` -> y*) is spread over the main k-steps: pairs
-// [8s/NKH, 8(s+1)/NKH) are finished before the MFMAs of k-step s, so a pending tile that feeds this tile's last two
-// k-steps is ready in time.  DMA: this tile issues the pieces [PD, NB) (+2 if extraB) of chunk T+1 before its
+// it holds the next tile's.  The epilogue of the PREVIOUS tile (`prev` -> y*) is spread over the main k-steps (pair p
+// in k-step floor(p*(NKH-1)/8)), so a pending tile that feeds this tile's last two k-steps is ready in time.  DMA: this tile issues the pieces [PD, NB) (+2 if extraB) of chunk T+1 before its
 // barrier and, after it, pieces [0, min(PD, NA)) of chunk T+2 (NA pieces per wave, +2 if extraA; NA = 0: none).
 // HASNEXT: a tile follows in this pass (its first fragments are prefetched).
 template <int NKP, int NKH, int NKD, int PHASE, bool X3, bool PEND, int NB, int NA, bool HASNEXT, class WalkerT>
@@ -235,6 +234,16 @@ __device__ __forceinline__ void tile_mma(WalkerT& wk, Frags& F, int lane, bool u
 #endif
             if (NA > 0) wk.begin(na_override >= 0 ? na_override : NA + (extraA ? 2 : 0), wk.b);
         }
+        // first MFMA of the k-step (hi.hi); everything else of the k-step is issued behind it, while it executes
+        const int use = (PHASE + q) % R;
+        if (q == 0 && !(NKP > 0 && pre_done)) {
+            f16v zero;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) zero[r] = 0.f;
+            cur.a = __builtin_amdgcn_mfma_f32_32x32x16_f16(F.hi[use], *Xh, zero, 0, 0, 0);
+        } else {
+            cur.a = __builtin_amdgcn_mfma_f32_32x32x16_f16(F.hi[use], *Xh, cur.a, 0, 0, 0);
+        }
         // DMA pieces: the rest of chunk T+1 before the barrier (spread over k-steps 0..QSYNC-1), the head of chunk T+2 after
         if (q < QSYNC && NB > PD) {
             constexpr int REST = NB - PD;
@@ -250,9 +259,9 @@ __device__ __forceinline__ void tile_mma(WalkerT& wk, Frags& F, int lane, bool u
 #else
         if (q + PD < NQ) {
 #endif
-            const int slot = (PHASE + q + PD) % R;
-            F.hi[slot] = *reinterpret_cast<const h8*>(cbase + (2 * (q + PD)) * kTileBytes);
+            const int slot = (PHASE + q + PD) % R;   // lo first: the first MFMA of the k-step needs hi, so one wait covers both
             if (X3) F.lo[slot] = *reinterpret_cast<const h8*>(cbase + (2 * (q + PD) + 1) * kTileBytes);
+            F.hi[slot] = *reinterpret_cast<const h8*>(cbase + (2 * (q + PD)) * kTileBytes);
 #ifdef NWE_EXP_NOLDS
         } else if (false) {
 #else
@@ -266,33 +275,25 @@ __device__ __forceinline__ void tile_mma(WalkerT& wk, Frags& F, int lane, bool u
         if (PEND && q == 0) asm volatile("" :: "a"(prev.a));   // keeps the previous tile's MFMAs alive without an epilogue
 #else
         if (PEND && q < NKH) {
+            // pair p runs in k-step floor(p*(NKH-1)/8): all eight pairs are done one k-step before the tile's last, because
+            // the FIRST MFMA of a k-step is issued ahead of that k-step's epilogue share and may read the pending tile's
+            // output (k-steps NKH-2, NKH-1 of X when the pending tile closes the previous layer)
 #pragma unroll
-            for (int p = (8 * q) / NKH; p < (8 * (q + 1)) / NKH; ++p) finish_pair<X3>(prev, p, inv_scale, lower, y0h, y0l, y1h, y1l);
+            for (int p = 0; p < 8; ++p)
+                if ((p * (NKH - 1)) / 8 == q) finish_pair<X3>(prev, p, inv_scale, lower, y0h, y0l, y1h, y1l);
         }
 #endif
-        const int use = (PHASE + q) % R;
-        if (q == 0) {
-            if (NKP > 0 && pre_done) {
-                mma3<X3>(F.hi[use], F.lo[use], *Xh, *Xl, cur.a);
-            } else {
-                f16v zero;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) zero[r] = 0.f;
-                cur.a = __builtin_amdgcn_mfma_f32_32x32x16_f16(F.hi[use], *Xh, zero, 0, 0, 0);
-                if (X3) {
-                    cur.a = __builtin_amdgcn_mfma_f32_32x32x16_f16(F.lo[use], *Xh, cur.a, 0, 0, 0);
-                    cur.a = __builtin_amdgcn_mfma_f32_32x32x16_f16(F.hi[use], *Xl, cur.a, 0, 0, 0);
-                }
-            }
-        } else {
-            mma3<X3>(F.hi[use], F.lo[use], *Xh, *Xl, cur.a);
+        if (X3) {
+            cur.a = __builtin_amdgcn_mfma_f32_32x32x16_f16(F.lo[use], *Xh, cur.a, 0, 0, 0);
+            cur.a = __builtin_amdgcn_mfma_f32_32x32x16_f16(F.hi[use], *Xl, cur.a, 0, 0, 0);
         }
-        // Pin the issue order of this k-step (LLVM SchedGroupMask: 0x100 DS read, 0x8 MFMA, 0x2 VALU): the fragment
-        // reads first, then each MFMA followed by a few epilogue VALU ops that execute while the matrix pipe works.
-        // Without this hipcc sinks the reads next to their use and clusters the epilogue.
-        if (q + PD < NQ || HASNEXT) __builtin_amdgcn_sched_group_barrier(0x100, X3 ? 2 : 1, 0);
-        constexpr int V = PEND ? ((NKH >= 16) ? (X3 ? 2 : 6) : ((NKH >= 8) ? (X3 ? 4 : 12) : 8)) : 0;
+        // Pin the issue order of this k-step (LLVM SchedGroupMask: 0x100 DS read, 0x8 MFMA, 0x2 VALU): first MFMA, the
+        // fragment reads, then the epilogue VALU ops of this k-step in equal shares behind each MFMA, where they execute
+        // while the matrix pipe works.  Without this hipcc sinks the reads next to their use and clusters the epilogue.
+        constexpr int VPK = PEND ? (X3 ? 16 : 9) * (8 / (NKH < 8 ? NKH : 8) > 1 ? 8 / NKH : 1) : 0;   // ~VALU ops per k-step
+        constexpr int V = X3 ? (VPK + 2) / 3 : VPK;
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        if (q + PD < NQ || HASNEXT) __builtin_amdgcn_sched_group_barrier(0x100, X3 ? 2 : 1, 0);
         if (V && q < NKH) __builtin_amdgcn_sched_group_barrier(0x002, V, 0);
         if (X3) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
