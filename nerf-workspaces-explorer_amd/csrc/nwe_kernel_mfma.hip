@@ -71,16 +71,27 @@ __device__ __forceinline__ float pend_value(const Pend& t, int r, float inv_scal
 
 // Epilogue of elements 2p, 2p+1 of a pending tile: v = max(acc/scale + bias, lower), hi = fp16(v), lo = fp16(v - hi).
 // Register r of the tile is element r&7 of the (r>>3)-th of its two output k-steps.
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+
 template <bool X3>
 __device__ __forceinline__ void finish_pair(const Pend& t, int p, float inv_scale, float lower, h8& hi0, h8& lo0, h8& hi1,
                                             h8& lo1) {
-#pragma unroll
-    for (int e = 2 * p; e < 2 * p + 2; ++e) {
-        const float v = fmaxf(pend_value(t, e, inv_scale), lower);
-        const _Float16 h = (_Float16)v;
-        const _Float16 l = X3 ? (_Float16)__builtin_fmaf((float)h, -1.f, v) : (_Float16)0.f;   // v_fma_mix: no separate cvt
-        if (e < 8) { hi0[e] = h; lo0[e] = l; } else { hi1[e - 8] = h; lo1[e - 8] = l; }
-    }
+    const float v0 = fmaxf(pend_value(t, 2 * p, inv_scale), lower);
+    const float v1 = fmaxf(pend_value(t, 2 * p + 1, inv_scale), lower);
+    h2 hh;
+    hh[0] = (_Float16)v0; hh[1] = (_Float16)v1;                       // one v_cvt_pk_f16_f32
+    h2 ll;
+    ll[0] = X3 ? (_Float16)(v0 - (float)hh[0]) : (_Float16)0.f;
+    ll[1] = X3 ? (_Float16)(v1 - (float)hh[1]) : (_Float16)0.f;
+    // materialise the packed dwords HERE: left alone, the packing of a whole tile is deferred to its end, where it
+    // forms a 16-instruction burst behind the last MFMA
+    uint32_t ph = __builtin_bit_cast(uint32_t, hh), pl = __builtin_bit_cast(uint32_t, ll);
+    asm volatile("" : "+v"(ph), "+v"(pl));
+    hh = __builtin_bit_cast(h2, ph);
+    ll = __builtin_bit_cast(h2, pl);
+    const int e = 2 * p;
+    if (e < 8) { hi0[e] = hh[0]; hi0[e + 1] = hh[1]; lo0[e] = ll[0]; lo0[e + 1] = ll[1]; }
+    else { hi1[e - 8] = hh[0]; hi1[e - 7] = hh[1]; lo1[e - 8] = ll[0]; lo1[e - 7] = ll[1]; }
 }
 
 template <bool X3>
@@ -280,7 +291,12 @@ __device__ __forceinline__ void tile_mma(WalkerT& wk, Frags& F, int lane, bool u
             // output (k-steps NKH-2, NKH-1 of X when the pending tile closes the previous layer)
 #pragma unroll
             for (int p = 0; p < 8; ++p)
-                if ((p * (NKH - 1)) / 8 == q) finish_pair<X3>(prev, p, inv_scale, lower, y0h, y0l, y1h, y1l);
+                if ((p * (NKH - 1)) / 8 == q) {
+                    finish_pair<X3>(prev, p, inv_scale, lower, y0h, y0l, y1h, y1l);
+                    // park the first output k-step in the accumulator file as soon as it is complete (pinning a partly
+                    // filled vector makes the allocator copy whole tuples); the second one is pinned at the tile's end
+                    if (p == 3) asm volatile("" : "+a"(y0h), "+a"(y0l));
+                }
         }
 #endif
         if (X3) {
@@ -312,7 +328,7 @@ __device__ __forceinline__ void tile_mma(WalkerT& wk, Frags& F, int lane, bool u
     // The "a" constraint also parks the finished fragments in the accumulator half of the register file, where the
     // MFMAs read them directly; as plain VGPR values the allocator spills half of them there anyway and copies each
     // back (4 v_accvgpr_read + s_nop) in front of every MFMA that uses it.
-    if (PEND) asm volatile("" : "+a"(y0h), "+a"(y0l), "+a"(y1h), "+a"(y1l));
+    if (PEND) asm volatile("" : "+a"(y1h), "+a"(y1l));
 #ifdef NWE_STAMPS
     { const unsigned long long t = __builtin_amdgcn_s_memtime(); wk.st_post += t - wk.st_t0; wk.st_t0 = t; }
 #endif
