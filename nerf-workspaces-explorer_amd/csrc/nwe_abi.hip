@@ -235,7 +235,6 @@ int launch(nwe_ctx* ctx, RenderArgs& a, int precision, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     a.t_vals = ctx->d_t; a.omt_vals = ctx->d_omt; a.u_vals = ctx->d_u;
     a.n_samples = ctx->ns; a.n_importance = ctx->ni;
-    { const char* e = getenv("NWE_DEBUG"); a.dbg = e ? atoi(e) : 0; }
     {   // diagnostic builds: NWE_STAMPS_PTR carries a device pointer (decimal) to per-wave cycle sums
         const char* e = getenv("NWE_STAMPS_PTR");
         a.stamps = e ? reinterpret_cast<unsigned long long*>(strtoull(e, nullptr, 10)) : nullptr;

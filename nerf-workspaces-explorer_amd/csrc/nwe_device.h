@@ -32,7 +32,6 @@ struct RenderArgs {
     const float* u_vals;
     const float* z_fine_in;  // test hook: fine depths [n_rays, ns+ni] instead of importance sampling
     int n_samples, n_importance;
-    int dbg;                 // timing experiments only (NWE_DEBUG env)
     unsigned long long* stamps;  // diagnostic builds (-DNWE_STAMPS): per-wave cycle sums, else unused
     nwe_outputs out;
 };

@@ -127,7 +127,7 @@ struct Walker {
     const float* bias_tab;   // LDS bias table of the current network, 32 floats per chunk
     int chunk;               // index of the chunk being consumed
     int b;                   // buffer holding the chunk being consumed
-    int wave, dbg;
+    int wave;
     uint32_t lane_off;       // lane * 16
     const uint8_t* blk_src;  // this wave's quarter of the chunk being streamed (uniform)
     uint32_t blk_dst;
@@ -538,7 +538,7 @@ __global__ void __launch_bounds__(256) render_mfma_kernel(RenderArgs a, NetMfma 
 
     Walker<S::CHUNK_BYTES> wk;
     wk.buf0 = smem; wk.lds_chunks = (uint32_t)(uintptr_t)(LDS_AS char*)smem;
-    wk.b = 0; wk.wave = wave; wk.lane_off = lane * 16; wk.dbg = a.dbg;
+    wk.b = 0; wk.wave = wave; wk.lane_off = lane * 16;
 
     // gamma(d): once per ray (model_utils.py:23-25 re-embeds the same direction for every sample)
     h8 GDhi[S::KD], GDlo[S::KD];

@@ -67,8 +67,10 @@ __global__ void selftest_kernel(float* d1 /*32x32*/, float* d2 /*32x32*/, float*
         const uint32_t lane_off = lane * 16;
         const char* src = reinterpret_cast<const char*>(pattern);
         const uint32_t dst = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)s_buf2;
-        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1\n\tglobal_load_lds_dwordx4 %0, %1 offset:1024"
-                     :: "v"(lane_off), "s"(src), "s"(dst) : "memory", "m0");
+        uint32_t keep;   // M0 is compiler-reserved: saved and restored inside the statement, as the render kernel does
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\t"
+                     "global_load_lds_dwordx4 %1, %2 offset:1024\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(lane_off), "s"(src), "s"(dst) : "memory");
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
