@@ -69,29 +69,149 @@ __device__ __forceinline__ float pend_value(const Pend& t, int r, float inv_scal
     return __builtin_fmaf(t.a[r], inv_scale, bb);
 }
 
-// Epilogue of elements 2p, 2p+1 of a pending tile: v = max(acc/scale + bias, lower), hi = fp16(v), lo = fp16(v - hi).
-// Register r of the tile is element r&7 of the (r>>3)-th of its two output k-steps.
 typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 
+// Epilogue of a pending tile, one ELEMENT per call so that its ~7 VALU ops per element can be spread evenly over the
+// k-steps of the next tile: v = max(acc/scale + bias, lower); every second call packs the pair: hi = fp16(v),
+// lo = fp16(v - hi).  Register r of the tile is element r&7 of the (r>>3)-th of its two output k-steps.
 template <bool X3>
-__device__ __forceinline__ void finish_pair(const Pend& t, int p, float inv_scale, float lower, h8& hi0, h8& lo0, h8& hi1,
-                                            h8& lo1) {
-    const float v0 = fmaxf(pend_value(t, 2 * p, inv_scale), lower);
-    const float v1 = fmaxf(pend_value(t, 2 * p + 1, inv_scale), lower);
-    h2 hh;
-    hh[0] = (_Float16)v0; hh[1] = (_Float16)v1;                       // one v_cvt_pk_f16_f32
-    h2 ll;
-    ll[0] = X3 ? (_Float16)(v0 - (float)hh[0]) : (_Float16)0.f;
-    ll[1] = X3 ? (_Float16)(v1 - (float)hh[1]) : (_Float16)0.f;
-    // materialise the packed dwords HERE: left alone, the packing of a whole tile is deferred to its end, where it
-    // forms a 16-instruction burst behind the last MFMA
-    uint32_t ph = __builtin_bit_cast(uint32_t, hh), pl = __builtin_bit_cast(uint32_t, ll);
-    asm volatile("" : "+v"(ph), "+v"(pl));
-    hh = __builtin_bit_cast(h2, ph);
-    ll = __builtin_bit_cast(h2, pl);
-    const int e = 2 * p;
-    if (e < 8) { hi0[e] = hh[0]; hi0[e + 1] = hh[1]; lo0[e] = ll[0]; lo0[e + 1] = ll[1]; }
-    else { hi1[e - 8] = hh[0]; hi1[e - 7] = hh[1]; lo1[e - 8] = ll[0]; lo1[e - 7] = ll[1]; }
+__device__ __forceinline__ void finish_elem(const Pend& t, int e, float inv_scale, float lower, float& keep, h8& hi0, h8& lo0,
+                                            h8& hi1, h8& lo1) {
+    const float v = fmaxf(pend_value(t, e, inv_scale), lower);
+    if ((e & 1) == 0) { keep = v; return; }
+    const float v0 = keep, v1 = v;
+    h2 hp;
+    hp[0] = (_Float16)v0; hp[1] = (_Float16)v1;                        // one v_cvt_pk_f16_f32
+    const _Float16 h0 = hp[0], h1 = hp[1];
+    _Float16 l0 = (_Float16)0.f, l1 = (_Float16)0.f;
+    if (X3) {
+        // residual v - hi as fma(hi, -1, v) with the fp16 half read in place: v_fma_mix_f32 instead of v_cvt_f32_f16 +
+        // v_sub_f32 (same single rounding).  hipcc does not select it from C, hence the asm.
+        const uint32_t hw = __builtin_bit_cast(uint32_t, hp);
+        float r0, r1;
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(hw), "v"(v0));
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(hw), "v"(v1));
+        l0 = (_Float16)r0; l1 = (_Float16)r1;
+    }
+    if (e < 8) { hi0[e - 1] = h0; hi0[e] = h1; lo0[e - 1] = l0; lo0[e] = l1; }
+    else { hi1[e - 9] = h0; hi1[e - 8] = h1; lo1[e - 9] = l0; lo1[e - 8] = l1; }
+}
+
+// ---- staged epilogue ----------------------------------------------------------------------------------------------
+// With one wave per SIMD an instruction costs 4 issue cycles, a VALU op that consumes the result of the instruction right
+// in front of it 8, and about six independent ones hide behind one 32-cycle MFMA (tools/ubench/mfma_issue.hip).  The
+// epilogue of a pending tile is therefore cut into STAGES of mutually independent ops over a group of elements, one stage
+// per MFMA gap: read accumulators | fma | max | pack hi | residual | pack lo | park hi | park lo.  Groups follow each other
+// from gap 1 on; a plan exists when all of it fits in front of the k-steps that consume the outputs.
+struct Epi {
+    float v[16];        // activation in fp32
+    float r[16];        // residual v - hi
+    uint32_t hp[8];     // packed fp16 pairs: hi
+    uint32_t lp[8];     // lo
+};
+
+// PM: bit q set = k-step q issues a DMA piece.  A piece costs ~16 issue cycles (it is priced like a four-dword store),
+// so in the three-pass kernel it has the gap behind the k-step's second MFMA to itself.
+template <bool X3, int NKH, int NQ, bool FEEDS, uint32_t PM>
+struct EpiPlan {
+    static constexpr int GPK = X3 ? 3 : 1;                 // MFMA gaps per k-step
+    static constexpr int NS = X3 ? 8 : 5;                  // stages per group
+    static constexpr int NGAPS = GPK * NQ;
+    static constexpr int D0 = FEEDS ? GPK * (NKH - 2) - 1 : NGAPS - 1;   // last gap for outputs 0..7
+    static constexpr int D1 = FEEDS ? GPK * (NKH - 1) - 1 : NGAPS - 1;   // ... 8..15
+    static constexpr bool usable(int gi) { return gi >= 1 && gi < NGAPS && !(X3 && gi % GPK == 1 && ((PM >> (gi / GPK)) & 1u)); }
+    static constexpr int gap_of(int n) {                    // gap of the n-th stage slot
+        int c = -1;
+        for (int gi = 0; gi < NGAPS; ++gi)
+            if (usable(gi) && ++c == n) return gi;
+        return 1 << 20;
+    }
+    static constexpr bool fits(int ng) { return gap_of((ng >= 2 ? ng / 2 : 1) * NS - 1) <= D0 && gap_of(ng * NS - 1) <= D1; }
+    static constexpr int NG = fits(4) ? 4 : (fits(2) ? 2 : (fits(1) ? 1 : 0));
+    static constexpr bool STAGED = NG > 0;
+    static constexpr int GS = STAGED ? 16 / NG : 16;
+    static constexpr int slot_at(int gi) {                  // stage slot executed in gap gi, or -1
+        if (!usable(gi)) return -1;
+        int c = 0;
+        for (int g = 0; g < gi; ++g) c += usable(g) ? 1 : 0;
+        return c < NG * NS ? c : -1;
+    }
+};
+
+__device__ __forceinline__ h8 pack4(uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
+    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+    u4 t = {a, b, c, d};
+    return __builtin_bit_cast(h8, t);
+}
+
+// Stage ST of group G of the plan.
+template <class P, bool X3, int G, int ST>
+__device__ __forceinline__ void epi_stage(const Pend& t, Epi& E, float inv_scale, float lower, h8& y0h, h8& y0l, h8& y1h, h8& y1l) {
+    constexpr int st = ST, e0 = G * P::GS;
+    constexpr int ST_PACK = 3, ST_RES = 4, ST_PACKLO = 5, ST_PARK = X3 ? 6 : 4;
+    if (st == 0) {
+#pragma unroll
+        for (int e = e0; e < e0 + P::GS; ++e) {
+            float a = t.a[e];
+            asm volatile("" : "+v"(a));   // the accumulator-file read happens HERE, not fused in front of its fma
+            E.v[e] = a;
+        }
+    } else if (st == 1) {
+#pragma unroll
+        for (int e = e0; e < e0 + P::GS; ++e) {
+            const float4 b = t.bias[e >> 2];
+            const float bb = (e & 3) == 0 ? b.x : ((e & 3) == 1 ? b.y : ((e & 3) == 2 ? b.z : b.w));
+            E.v[e] = __builtin_fmaf(E.v[e], inv_scale, bb);
+        }
+    } else if (st == 2) {
+#pragma unroll
+        for (int e = e0; e < e0 + P::GS; ++e) E.v[e] = fmaxf(E.v[e], lower);
+    } else if (st == ST_PACK) {
+#pragma unroll
+        for (int p = e0 / 2; p < (e0 + P::GS) / 2; ++p) {
+            h2 hp;
+            hp[0] = (_Float16)E.v[2 * p]; hp[1] = (_Float16)E.v[2 * p + 1];   // one v_cvt_pk_f16_f32
+            E.hp[p] = __builtin_bit_cast(uint32_t, hp);
+            if (!X3) E.lp[p] = 0u;
+        }
+    } else if (X3 && st == ST_RES) {
+        // residual v - hi as fma(hi, -1, v) with the fp16 half read in place: v_fma_mix_f32 instead of v_cvt_f32_f16 +
+        // v_sub_f32 (same single rounding).  hipcc does not select it from C (it folds the -1 into a subtraction first).
+#pragma unroll
+        for (int p = e0 / 2; p < (e0 + P::GS) / 2; ++p) {
+            asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(E.r[2 * p]) : "v"(E.hp[p]), "v"(E.v[2 * p]));
+            asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(E.r[2 * p + 1]) : "v"(E.hp[p]), "v"(E.v[2 * p + 1]));
+        }
+    } else if (X3 && st == ST_PACKLO) {
+#pragma unroll
+        for (int p = e0 / 2; p < (e0 + P::GS) / 2; ++p) {
+            h2 lp;
+            lp[0] = (_Float16)E.r[2 * p]; lp[1] = (_Float16)E.r[2 * p + 1];
+            E.lp[p] = __builtin_bit_cast(uint32_t, lp);
+        }
+    } else if (st == ST_PARK || st == ST_PARK + 1) {
+        // Park finished output k-steps in the accumulator half of the register file, where the MFMAs read them directly
+        // (as plain VGPR values the allocator moves half of them there anyway and copies each back in front of its use):
+        // hi in this gap, lo in the next.  Output k-step 0 is complete with element 7, k-step 1 with element 15.
+        const bool lo = st != ST_PARK;
+        if (lo && !X3) return;
+        const int last = e0 + P::GS - 1;
+        if (last == 7 || (P::GS == 16)) {
+            if (!lo) { y0h = pack4(E.hp[0], E.hp[1], E.hp[2], E.hp[3]); asm volatile("" : "+a"(y0h)); }
+            else     { y0l = pack4(E.lp[0], E.lp[1], E.lp[2], E.lp[3]); asm volatile("" : "+a"(y0l)); }
+        }
+        if (last == 15) {
+            if (!lo) { y1h = pack4(E.hp[4], E.hp[5], E.hp[6], E.hp[7]); asm volatile("" : "+a"(y1h)); }
+            else     { y1l = pack4(E.lp[4], E.lp[5], E.lp[6], E.lp[7]); asm volatile("" : "+a"(y1l)); }
+        }
+    }
+}
+
+// Gap GI (0-based over the tile's main k-steps) of the plan: the stage of one group, or nothing.
+template <class P, bool X3, int GI>
+__device__ __forceinline__ void epi_gap(const Pend& t, Epi& E, float inv_scale, float lower, h8& y0h, h8& y0l, h8& y1h, h8& y1l) {
+    constexpr int slot = P::slot_at(GI);
+    if constexpr (slot >= 0) epi_stage<P, X3, slot / P::NS, slot % P::NS>(t, E, inv_scale, lower, y0h, y0l, y1h, y1l);
 }
 
 template <bool X3>
@@ -108,9 +228,14 @@ __device__ __forceinline__ void mma3(const h8& a_hi, const h8& a_lo, const h8& x
 // LDS-DMA goes through inline asm: hipcc's waitcnt pass treats a builtin global_load_lds as an LDS store that may
 // alias every later ds_read of the same array and drains vmcnt(0) in front of the first one, which would serialise
 // the prefetch with the compute it is meant to hide behind.  The asm form is invisible to that pass; completion is
-// waited for by hand in sync() (s_waitcnt vmcnt(0) + barrier).  M0 carries the wave-uniform LDS destination and
-// is compiler-reserved, so it is saved and restored inside the statement.  Wave w streams the w-th quarter of a
-// chunk (n consecutive 1-KiB pieces): source = scalar base + lane*16, so a piece costs scalar instructions only.
+// waited for by hand in sync() (s_waitcnt vmcnt(0) + barrier).  Wave w streams the w-th quarter of a chunk (n
+// consecutive 1-KiB pieces): source = scalar base + lane*16, so a piece costs scalar instructions only.
+//
+// M0 carries the wave-uniform LDS destination.  With one wave per SIMD every instruction slot counts (a piece with M0
+// saved and restored around it is five), so M0 is OWNED by this kernel: it is written once per group of four pieces and
+// left there.  That is sound only while hipcc emits no M0 use of its own in this kernel (it has no reason to on gfx950:
+// no movrel, no GDS, no sendmsg) - tests/test_abi.py::test_kernel_owns_m0 greps the generated assembly for exactly that,
+// and pieces of a group must be issued in order with no other group in between (tile_mma's static schedule does).
 //
 // Timeline (tile T consumes chunk T from buffer T&1; PD = fragment prefetch distance in k-steps):
 //   * ONE barrier per tile, PD k-steps before the tile's end.  Before it every wave waits for its own LDS reads
@@ -154,39 +279,80 @@ struct Walker {
 #endif
         const uint8_t* src = blk_src + (size_t)(i >> 2) * (4 * kTileBytes);
         const uint32_t dst = blk_dst + (i >> 2) * (4 * kTileBytes);
-        uint32_t keep;
         switch (i & 3) {
-#define NWE_GLDS(OFF)                                                                                                         \
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 offset:" #OFF "\n\ts_mov_b32 m0, %0" \
-                 : "=&s"(keep) : "v"(lane_off), "s"(src), "s"(dst) : "memory")
-            case 0: NWE_GLDS(0); break;
+#define NWE_GLDS(OFF) asm volatile("global_load_lds_dwordx4 %0, %1 offset:" #OFF :: "v"(lane_off), "s"(src) : "memory")
+            case 0:   // first piece of a group: point M0 at the group's LDS destination (one wait state before the DMA)
+                asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(lane_off), "s"(src), "s"(dst)
+                             : "memory");
+                break;
             case 1: NWE_GLDS(1024); break;
             case 2: NWE_GLDS(2048); break;
             default: NWE_GLDS(3072); break;
 #undef NWE_GLDS
         }
     }
+    template <bool LONG_TILE>
     __device__ __forceinline__ void sync() {
 #ifdef NWE_EXP_NOSYNC
         return;
 #endif
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __syncthreads();
+        // Own DMA pieces of chunk T+1 landed and own LDS reads done - on the long tiles EXCEPT the two reads just issued (the
+        // fragments of this chunk's last k-step, one k-step ago): waiting for those too costs an LDS round trip per tile
+        // (5 % of the frame time).  They read tiles 2*NQ-2, 2*NQ-1 of the buffer this barrier releases; the pieces that
+        // overwrite those two tiles are the last two of the wave owning the chunk's last quarter and are issued >= 3
+        // k-steps (9 MFMAs, ~300 cycles) into the next tile, while the reads were handed to the LDS unit before the
+        // barrier and the LDS services its queue in order.  Short tiles re-fill the buffer right behind the barrier and
+        // keep the full wait.
+        if (LONG_TILE) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(2)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        asm volatile("s_barrier" ::: "memory");
     }
     __device__ __forceinline__ void tile_done() { b ^= 1; ++chunk; }
 };
 
+// Compile-time loop: f(integral_constant<int, I>) for I in [I0, N).
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
 constexpr int PD = 3;   // A fragments are read PD k-steps ahead of their MFMAs
 struct Frags { h8 hi[PD + 1], lo[PD + 1]; };   // ring, slot = (k-step counter) mod (PD+1)
+
+// Which k-steps of a tile issue DMA pieces (static; tile_mma and the epilogue plan both read it).  The pieces [PD, NB) of
+// chunk T+1 go from k-step 0 on, one per k-step on the long tiles - as early as possible, the barrier at k-step QSYNC =
+// NQ - PD waits for them - followed by the two extra pieces of a skip-layer chunk (their slots are reserved whether or not
+// the chunk has them); after the barrier come the first min(PD, NA) pieces of chunk T+2.
+template <int NB, int NA, int NQ>
+struct DmaPlan {
+    static constexpr int QSYNC = NQ - PD;
+    static constexpr int REST = NB > PD ? NB - PD : 0;
+    static constexpr int TOT = REST > 0 ? REST + 2 : 0;                                   // logical slots: pieces, then the two extras
+    static constexpr int PPK = TOT == 0 ? 0 : (TOT + (QSYNC > 0 ? QSYNC : 1) - 1) / (QSYNC > 0 ? QSYNC : 1);   // slots per k-step (1 on long tiles)
+    static_assert(TOT == 0 || QSYNC > 0, "no k-step in front of the barrier for the DMA pieces");
+    static constexpr int lo(int q) { return q * PPK < TOT ? q * PPK : TOT; }
+    static constexpr uint32_t mask() {
+        uint32_t m = 0;
+        for (int q = 0; q < NQ; ++q) {
+            const bool pre = q < QSYNC && lo(q + 1) > lo(q);
+            const bool post = q >= QSYNC && NA > 0 && q - QSYNC < (NA < PD ? NA : PD);
+            if (pre || post) m |= 1u << q;
+        }
+        return m;
+    }
+};
 
 // One 32-row tile = NKP optional "pre" k-steps (gamma(x) of the skip layer, taken if use_g) + NKH main k-steps over
 // X + NKD "post" k-steps (gamma(d) of the view layer).  Chunk layout in that order, (hi, lo) tile pair per k-step,
 // lane-linear.  On entry the fragment ring holds this tile's first PD k-steps in slots PHASE..PHASE+PD-1; on exit
-// it holds the next tile's.  The epilogue of the PREVIOUS tile (`prev` -> y*) is spread over the main k-steps (pair p
-// in k-step floor(p*(NKH-1)/8)), so a pending tile that feeds this tile's last two k-steps is ready in time.  DMA: this tile issues the pieces [PD, NB) (+2 if extraB) of chunk T+1 before its
+// it holds the next tile's.  The epilogue of the PREVIOUS tile (`prev` -> y*) is spread over the main k-steps (element
+// e in k-step floor(e*(NKH-1)/16)), so a pending tile that feeds this tile's last two k-steps is ready in time.  DMA: this tile issues the pieces [PD, NB) (+2 if extraB) of chunk T+1 before its
 // barrier and, after it, pieces [0, min(PD, NA)) of chunk T+2 (NA pieces per wave, +2 if extraA; NA = 0: none).
 // HASNEXT: a tile follows in this pass (its first fragments are prefetched).
-template <int NKP, int NKH, int NKD, int PHASE, bool X3, bool PEND, int NB, int NA, bool HASNEXT, class WalkerT>
+template <int NKP, int NKH, int NKD, int PHASE, bool X3, bool PEND, int NB, int NA, bool HASNEXT, bool FEEDS = false, class WalkerT>
 __device__ __forceinline__ void tile_mma(WalkerT& wk, Frags& F, int lane, bool use_g, bool extraB, bool extraA, const h8* Ghi,
                                          const h8* Glo, const h8* Xhi, const h8* Xlo, const h8* Dhi, const h8* Dlo, Pend& cur,
                                          const Pend& prev, float inv_scale, float lower, h8& y0h, h8& y0l, h8& y1h, h8& y1l, int na_override = -1) {
@@ -203,6 +369,8 @@ __device__ __forceinline__ void tile_mma(WalkerT& wk, Frags& F, int lane, bool u
     const char* cbase = wk.cur() + lane * 16;
     const char* nbase = wk.next() + lane * 16;
     bool pre_done = false;
+    float ekeep = 0.f;   // even element of the epilogue pair in flight (unstaged fallback)
+    Epi E;
     if (NKP > 0) {
         if (use_g) {   // pre segment: positions 0..NKP-1 of the chunk; reads stay inside this chunk
 #pragma unroll
@@ -231,15 +399,15 @@ __device__ __forceinline__ void tile_mma(WalkerT& wk, Frags& F, int lane, bool u
             pre_done = true;
         }
     }
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) {
+    static_for<0, NQ>([&](auto qc) __attribute__((always_inline)) {
+        constexpr int q = decltype(qc)::value;
         const h8* Xh = q < NKH ? &Xhi[q] : &Dhi[q - NKH];
         const h8* Xl = q < NKH ? &Xlo[q] : &Dlo[q - NKH];
         if (q == QSYNC) {
 #ifdef NWE_STAMPS
             { const unsigned long long t = __builtin_amdgcn_s_memtime(); wk.st_pre += t - wk.st_t0; wk.st_t0 = t; }
 #endif
-            wk.sync();
+            wk.template sync<(X3 && NQ >= 16)>();
 #ifdef NWE_STAMPS
             { const unsigned long long t = __builtin_amdgcn_s_memtime(); wk.st_wait += t - wk.st_t0; wk.st_t0 = t; }
 #endif
@@ -255,15 +423,20 @@ __device__ __forceinline__ void tile_mma(WalkerT& wk, Frags& F, int lane, bool u
         } else {
             cur.a = __builtin_amdgcn_mfma_f32_32x32x16_f16(F.hi[use], *Xh, cur.a, 0, 0, 0);
         }
-        // DMA pieces: the rest of chunk T+1 before the barrier (spread over k-steps 0..QSYNC-1), the head of chunk T+2 after
-        if (q < QSYNC && NB > PD) {
-            constexpr int REST = NB - PD;
-            constexpr int SPAN = QSYNC > 0 ? QSYNC : 1;
+        // DMA piece of this k-step (DmaPlan).  In the three-pass kernel it goes behind the SECOND MFMA: a piece costs ~16
+        // issue cycles and next to the two fragment reads it would overrun the 32 cycles of the MFMA it hides behind.
+        auto dma = [&]() __attribute__((always_inline)) {
+            using DP = DmaPlan<NB, NA, NQ>;
+            if constexpr (q < QSYNC && DP::TOT > 0) {
 #pragma unroll
-            for (int i = (q * REST + SPAN - 1) / SPAN; i < ((q + 1) * REST + SPAN - 1) / SPAN; ++i) wk.piece(PD + i);
-            if (q == 0 && extraB) { wk.piece(NB); wk.piece(NB + 1); }
-        }
-        if (q >= QSYNC && NA > 0 && q - QSYNC < (NA < PD ? NA : PD)) wk.piece(q - QSYNC);
+                for (int j = DP::lo(q); j < DP::lo(q + 1); ++j) {
+                    if (j < DP::REST) wk.piece(PD + j);
+                    else if (extraB) wk.piece(NB + j - DP::REST);
+                }
+            }
+            if constexpr (q >= QSYNC && NA > 0 && q - QSYNC < (NA < PD ? NA : PD)) wk.piece(q - QSYNC);
+        };
+        if constexpr (!X3) dma();
         // fragment read of position q+PD: this chunk, or the next tile's first k-steps (visible since the barrier)
 #ifdef NWE_EXP_NOLDS
         if (false) {
@@ -282,46 +455,44 @@ __device__ __forceinline__ void tile_mma(WalkerT& wk, Frags& F, int lane, bool u
             if (X3) F.lo[slot] = *reinterpret_cast<const h8*>(nbase + (2 * (q + PD - NQ) + 1) * kTileBytes);
             F.hi[slot] = *reinterpret_cast<const h8*>(nbase + (2 * (q + PD - NQ)) * kTileBytes);
         }
-#ifdef NWE_EXP_NOEPI
-        if (PEND && q == 0) asm volatile("" :: "a"(prev.a));   // keeps the previous tile's MFMAs alive without an epilogue
+        using Plan = EpiPlan<X3, NKH, NQ, FEEDS, DmaPlan<NB, NA, NQ>::mask()>;
+        constexpr int GPK = Plan::GPK;
+#ifdef NWE_EXP_NOEPI   // timing experiment: no epilogue at all (results are garbage); the pending accumulator is kept alive
+        if constexpr (PEND && q == 0) asm volatile("" :: "a"(prev.a));
+#define NWE_EPI_ON false
 #else
-        if (PEND && q < NKH) {
-            // pair p runs in k-step floor(p*(NKH-1)/8): all eight pairs are done one k-step before the tile's last, because
-            // the FIRST MFMA of a k-step is issued ahead of that k-step's epilogue share and may read the pending tile's
-            // output (k-steps NKH-2, NKH-1 of X when the pending tile closes the previous layer)
+#define NWE_EPI_ON true
+#endif
+        if constexpr (NWE_EPI_ON && PEND && Plan::STAGED) epi_gap<Plan, X3, GPK * q>(prev, E, inv_scale, lower, y0h, y0l, y1h, y1l);
+        if (NWE_EPI_ON && PEND && !Plan::STAGED && q < NKH) {
+            // short tiles whose outputs feed their own last k-steps have no room for the staged plan: element e runs in
+            // k-step floor(e*(NKH-1)/16), so all sixteen are done one k-step before the tile's last
 #pragma unroll
-            for (int p = 0; p < 8; ++p)
-                if ((p * (NKH - 1)) / 8 == q) {
-                    finish_pair<X3>(prev, p, inv_scale, lower, y0h, y0l, y1h, y1l);
-                    // park the first output k-step in the accumulator file as soon as it is complete (pinning a partly
-                    // filled vector makes the allocator copy whole tuples); the second one is pinned at the tile's end
-                    if (p == 3) asm volatile("" : "+a"(y0h), "+a"(y0l));
+            for (int e = 0; e < 16; ++e)
+                if ((e * (NKH - 1)) / 16 == q) {
+                    finish_elem<X3>(prev, e, inv_scale, lower, ekeep, y0h, y0l, y1h, y1l);
+                    if (e == 7) asm volatile("" : "+a"(y0h), "+a"(y0l));
                 }
         }
-#endif
-        if (X3) {
-            cur.a = __builtin_amdgcn_mfma_f32_32x32x16_f16(F.lo[use], *Xh, cur.a, 0, 0, 0);
-            cur.a = __builtin_amdgcn_mfma_f32_32x32x16_f16(F.hi[use], *Xl, cur.a, 0, 0, 0);
-        }
-        // Pin the issue order of this k-step (LLVM SchedGroupMask: 0x100 DS read, 0x8 MFMA, 0x2 VALU): first MFMA, the
-        // fragment reads, then the epilogue VALU ops of this k-step in equal shares behind each MFMA, where they execute
-        // while the matrix pipe works.  Without this hipcc sinks the reads next to their use and clusters the epilogue.
-        constexpr int VPK = PEND ? (X3 ? 16 : 9) * (8 / (NKH < 8 ? NKH : 8) > 1 ? 8 / NKH : 1) : 0;   // ~VALU ops per k-step
-        constexpr int V = X3 ? (VPK + 2) / 3 : VPK;
+        // Issue order: each MFMA opens its own scheduling region (hard fence behind every gap), the fragment reads and the
+        // DMA piece follow the first one.  Inside a region the ops are independent of each other by construction, so the
+        // order hipcc picks there costs nothing; without the fences it sinks the prefetch reads (issued PD k-steps early
+        // on purpose) to their first use and clusters the epilogue into dependent chains at the end of the tile.
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         if (q + PD < NQ || HASNEXT) __builtin_amdgcn_sched_group_barrier(0x100, X3 ? 2 : 1, 0);
-        if (V && q < NKH) __builtin_amdgcn_sched_group_barrier(0x002, V, 0);
         if (X3) {
+            __builtin_amdgcn_sched_barrier(0);
+            cur.a = __builtin_amdgcn_mfma_f32_32x32x16_f16(F.lo[use], *Xh, cur.a, 0, 0, 0);
+            dma();
+            if constexpr (NWE_EPI_ON && PEND && Plan::STAGED) epi_gap<Plan, X3, GPK * q + 1>(prev, E, inv_scale, lower, y0h, y0l, y1h, y1l);
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            if (V && q < NKH) __builtin_amdgcn_sched_group_barrier(0x002, V, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            cur.a = __builtin_amdgcn_mfma_f32_32x32x16_f16(F.hi[use], *Xl, cur.a, 0, 0, 0);
+            if constexpr (NWE_EPI_ON && PEND && Plan::STAGED) epi_gap<Plan, X3, GPK * q + 2>(prev, E, inv_scale, lower, y0h, y0l, y1h, y1l);
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            if (V && q < NKH) __builtin_amdgcn_sched_group_barrier(0x002, V, 0);
         }
-        // Hard fence between k-steps: without it the scheduler fills the "DS read" groups with whatever reads it likes
-        // and sinks the prefetch reads (issued PD k-steps early on purpose) down to their first use, so that every
-        // k-step waits a full LDS latency.
         __builtin_amdgcn_sched_barrier(0);
-    }
+    });
     // Keep the epilogue HERE: its results are only consumed by the next layer, so without a use at this point
     // LLVM sinks the whole epilogue of every tile of a layer to the layer's end (and keeps all their accumulators
     // alive), which is exactly the un-overlapped VALU block this structure is meant to remove.
@@ -358,7 +529,7 @@ __device__ __forceinline__ void layer(WalkerT& wk, Frags& F, int lane, bool use_
             constexpr int NB0 = PASS_START ? 0 : N_THIS;
             if constexpr (PEND0) {
                 constexpr int L = 2 * NT - 2;   // the previous layer has as many tiles as X has k-step pairs
-                tile_mma<NKP, NKH, 0, 0, X3, true, NB0, N_THIS, true>(wk, F, lane, use_g, ebB, ebA, Ghi, Glo, Xhi, Xlo, nullptr, nullptr,
+                tile_mma<NKP, NKH, 0, 0, X3, true, NB0, N_THIS, true, true>(wk, F, lane, use_g, ebB, ebA, Ghi, Glo, Xhi, Xlo, nullptr, nullptr,
                                                                       cur, prev, inv_scale, lower_prev, Xhi[L], Xlo[L], Xhi[L + 1], Xlo[L + 1]);
             } else {
                 h8 d0, d1, d2, d3;
@@ -486,7 +657,7 @@ __device__ __forceinline__ void mlp_eval(WalkerT& wk, Frags& F, int lane, float 
     {
         constexpr int LV = 2 * S::NTV - 2;
         static_assert((S::NTV * (S::KH + S::KD)) % (PD + 1) == 0, "the view tiles must restore the ring phase");
-        tile_mma<0, S::KV, 0, 0, X3, true, 0, 0, false>(wk, F, lane, false, false, false, nullptr, nullptr, Bhi, Blo, nullptr, nullptr, P1,
+        tile_mma<0, S::KV, 0, 0, X3, true, 0, 0, false, true>(wk, F, lane, false, false, false, nullptr, nullptr, Bhi, Blo, nullptr, nullptr, P1,
                                                         P0, inv_scale, 0.f, Bhi[LV], Blo[LV], Bhi[LV + 1], Blo[LV + 1]);
     }
     o_r = pend_value(P1, 0, inv_scale);
@@ -590,7 +761,7 @@ __global__ void __launch_bounds__(256) render_mfma_kernel(RenderArgs a, NetMfma 
 #ifdef NWE_STAMPS
             const unsigned long long t1 = __builtin_amdgcn_s_memtime();
 #endif
-            wk.sync();
+            wk.template sync<false>();
             Frags F;
 #pragma unroll
             for (int k = 0; k < PD; ++k) {

@@ -1,7 +1,7 @@
 """Summarise rocprofv3 --pmc CSV output for the render kernel (last dispatch): per-wave cycle shares."""
 import csv, collections, glob, sys
 for d in sys.argv[1:]:
-    for f in glob.glob(f"{d}/*/*_counter_collection.csv"):
+    for f in glob.glob(f"{d}/*_counter_collection.csv") + glob.glob(f"{d}/*/*_counter_collection.csv"):
         agg = collections.OrderedDict()
         for r in csv.DictReader(open(f)):
             if "render_mfma" not in r["Kernel_Name"]:
@@ -15,8 +15,8 @@ for d in sys.argv[1:]:
         print(d, {k: f"{v:.4g}" for k, v in c.items()})
         if "SQ_WAVE_CYCLES" in c:
             wc = c["SQ_WAVE_CYCLES"]
-            for k in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY"):
-                if k in c:
-                    print(f"   {k}: {c[k] / wc:.1%} of wave cycles")
+            for k, v in c.items():
+                if k not in ("SQ_WAVE_CYCLES", "SQ_VALU_MFMA_BUSY_CYCLES"):
+                    print(f"   {k}: {v / wc:.2%} of wave cycles")
             if "SQ_VALU_MFMA_BUSY_CYCLES" in c:
                 print(f"   MFMA busy: {c['SQ_VALU_MFMA_BUSY_CYCLES'] / (4 * wc):.1%} of wave cycles (1 wave per SIMD)")
