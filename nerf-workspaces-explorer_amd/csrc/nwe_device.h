@@ -185,6 +185,51 @@ struct FineSampler {
     }
 };
 
+// sin and cos of a * 2^b for b = 0..NB-1, a = v * first (first a power of two, so a is exact): the NB octaves of one
+// positional-encoding coordinate (nerf/models/embedding.py:36 evaluates sin/cos of the fp32 product x * 2^b, which is exact).
+// One fp64 evaluation at the lowest octave - two-constant Cody-Waite reduction by pi/2 (exact for |a| < 1.6e6), the
+// classic degree-13/12 minimax kernels on [-pi/4, pi/4] (error < 2^-57) - then double-angle steps in fp64, whose error
+// doubles per octave and stays below 1e-13 after nine of them; every result is rounded to fp32 once.  This replaces
+// 2*NB libm calls per coordinate (each with its own range reduction) and is at least as close to the reference's libm
+// as they were (nwe_selftest report[4]: max |err| vs fp64 in units of 1e-9).
+template <int NB>
+__device__ __forceinline__ void octave_sincos(float v, float first, float* sn, float* cs) {
+    const double a = (double)v * (double)first;
+    const double n = __builtin_rint(a * 6.36619772367581382433e-01);         // 2/pi
+    double r = __builtin_fma(-n, 1.57079632673412561417e+00, a);              // first 33 bits of pi/2: the product is exact
+    r = __builtin_fma(-n, 6.07710050650619224932e-11, r);
+    const double z = r * r;
+    double ps = 1.58969099521155010221e-10;
+    ps = __builtin_fma(ps, z, -2.50507602534068634195e-08);
+    ps = __builtin_fma(ps, z, 2.75573137070700676789e-06);
+    ps = __builtin_fma(ps, z, -1.98412698298579493134e-04);
+    ps = __builtin_fma(ps, z, 8.33333333332248946124e-03);
+    ps = __builtin_fma(ps, z, -1.66666666666666324348e-01);
+    const double sin_r = __builtin_fma(r * z, ps, r);
+    double pc = -1.13596475577881948265e-11;
+    pc = __builtin_fma(pc, z, 2.08757232129817482790e-09);
+    pc = __builtin_fma(pc, z, -2.75573143513906633035e-07);
+    pc = __builtin_fma(pc, z, 2.48015872894767294178e-05);
+    pc = __builtin_fma(pc, z, -1.38888888888741095749e-03);
+    pc = __builtin_fma(pc, z, 4.16666666666666019037e-02);
+    const double cos_r = __builtin_fma(z * z, pc, __builtin_fma(-0.5, z, 1.0));
+    const int q = (int)n & 3;                     // a = r + n*pi/2
+    double s = (q & 1) ? cos_r : sin_r;
+    double c = (q & 1) ? sin_r : cos_r;
+    if (q & 2) s = -s;
+    if ((q + 1) & 2) c = -c;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        sn[b] = (float)s;
+        cs[b] = (float)c;
+        if (b + 1 < NB) {
+            const double t = s * c, u = s * s;
+            s = t + t;                            // sin 2x = 2 sin x cos x
+            c = __builtin_fma(-2.0, u, 1.0);      // cos 2x = 1 - 2 sin^2 x
+        }
+    }
+}
+
 __device__ __forceinline__ bool bad(float x) { return !(fabsf(x) <= 3.402823466e38f); }  // NaN or inf
 
 // Writes the per-ray results of one pass into the fine (handler.py:263-266) or coarse (:257-260) slots

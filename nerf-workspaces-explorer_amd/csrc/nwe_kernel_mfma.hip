@@ -127,7 +127,7 @@ struct EpiPlan {
         return 1 << 20;
     }
     static constexpr bool fits(int ng) { return gap_of((ng >= 2 ? ng / 2 : 1) * NS - 1) <= D0 && gap_of(ng * NS - 1) <= D1; }
-    static constexpr int NG = fits(4) ? 4 : (fits(2) ? 2 : (fits(1) ? 1 : 0));
+    static constexpr int NG = fits(4) ? 4 : (fits(2) ? 2 : (fits(1) ? 1 : 0));   // 8 ops per gap (NG = 2) measures 4 % slower
     static constexpr bool STAGED = NG > 0;
     static constexpr int GS = STAGED ? 16 / NG : 16;
     static constexpr int slot_at(int gi) {                  // stage slot executed in gap gi, or -1
@@ -438,19 +438,11 @@ __device__ __forceinline__ void tile_mma(WalkerT& wk, Frags& F, int lane, bool u
         };
         if constexpr (!X3) dma();
         // fragment read of position q+PD: this chunk, or the next tile's first k-steps (visible since the barrier)
-#ifdef NWE_EXP_NOLDS
-        if (false) {
-#else
         if (q + PD < NQ) {
-#endif
             const int slot = (PHASE + q + PD) % R;   // lo first: the first MFMA of the k-step needs hi, so one wait covers both
             if (X3) F.lo[slot] = *reinterpret_cast<const h8*>(cbase + (2 * (q + PD) + 1) * kTileBytes);
             F.hi[slot] = *reinterpret_cast<const h8*>(cbase + (2 * (q + PD)) * kTileBytes);
-#ifdef NWE_EXP_NOLDS
-        } else if (false) {
-#else
         } else if (HASNEXT) {
-#endif
             const int slot = (PHASE + q + PD) % R;
             if (X3) F.lo[slot] = *reinterpret_cast<const h8*>(nbase + (2 * (q + PD - NQ) + 1) * kTileBytes);
             F.hi[slot] = *reinterpret_cast<const h8*>(nbase + (2 * (q + PD - NQ)) * kTileBytes);
@@ -560,17 +552,16 @@ __device__ __forceinline__ void encode(float vx, float vy, float vz, int h, h8* 
     float vals[NK * 8];
 #pragma unroll
     for (int i = 0; i < NK * 8; ++i) vals[i] = 0.f;
-    const float first = h ? (float)(1 << NB) : 1.f;   // 2^(NB*h): exact scaling
+    const float first = h ? (float)(1 << NB) : 1.f;   // 2^(NB*h): this lane half's lowest octave
 #pragma unroll
-    for (int bl = 0; bl < NB; ++bl) {
-        const float f = first * (float)(1 << bl);
+    for (int c = 0; c < 3; ++c) {
+        const float v = c == 0 ? vx : (c == 1 ? vy : vz);
+        float sn[NB], cs[NB];
+        octave_sincos<NB>(v, first, sn, cs);             // embedding.py:36: fn(x * freq) for freq = first * 2^bl
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const float v = c == 0 ? vx : (c == 1 ? vy : vz);
-            float sn, cs;
-            sincosf(v * f, &sn, &cs);                    // embedding.py:36: fn(x * freq), x*freq exact
-            vals[2 * (bl * 3 + c)] = sn;
-            vals[2 * (bl * 3 + c) + 1] = cs;
+        for (int bl = 0; bl < NB; ++bl) {
+            vals[2 * (bl * 3 + c)] = sn[bl];
+            vals[2 * (bl * 3 + c) + 1] = cs[bl];
         }
     }
     vals[6 * NB] = h ? vz : vx;

@@ -5,7 +5,7 @@
 //              packer's k permutation (hidden_col)
 //   report[2]  1 if fp16 subnormal MFMA operands are honoured, 0 if flushed to zero (informational)
 //   report[3]  mismatches of the LDS-DMA (global_load_lds_dwordx4) lane order: LDS[base + 16*lane]
-//   report[4]  max |sincosf - fp64| over arguments up to 1.1e3 rad, in units of 1e-9 (informational)
+//   report[4]  max |octave_sincos - fp64 libm| over the positional-encoding arguments (up to 1.1e3 rad), in units of 1e-9
 //   report[5]  max relative error of expf over [-20, 20], in units of 1e-9 (informational)
 //   report[6]  mismatches of the scalar-base + immediate-offset LDS-DMA form the render kernel uses: the instruction
 //              offset must advance BOTH the global source and the LDS destination
@@ -76,9 +76,10 @@ __global__ void selftest_kernel(float* d1 /*32x32*/, float* d2 /*32x32*/, float*
     __syncthreads();
     for (int k = threadIdx.x; k < 512; k += blockDim.x) { lds_out[k] = s_buf[k]; lds_out2[k] = s_buf2[k]; }
     for (int k = threadIdx.x; k < n; k += blockDim.x) {
-        float sn, cs;
-        sincosf(args[k], &sn, &cs);
-        sc[2 * k] = sn; sc[2 * k + 1] = cs;
+        // the render kernel's positional-encoding routine: five octaves from args[k] * (1 or 32)
+        float sn[5], cs[5];
+        nwe::octave_sincos<5>(args[k], (k & 1) ? 32.f : 1.f, sn, cs);
+        for (int b = 0; b < 5; ++b) { sc[10 * k + 2 * b] = sn[b]; sc[10 * k + 2 * b + 1] = cs[b]; }
         ex[k] = expf(-20.f + 40.f * (float)k / (float)n);
     }
 }
@@ -89,28 +90,28 @@ int run_selftest(int32_t* rep, hipStream_t stream) {
     for (int k = 0; k < 8; ++k) rep[k] = 0;
     const int n = 4096;
     std::vector<float> args(n);
-    for (int k = 0; k < n; ++k) {   // gamma(x) arguments: v*2^b with |v| <= 2.2, b <= 9
+    for (int k = 0; k < n; ++k) {   // gamma(x) coordinates |v| <= 2.2; the kernel evaluates octaves 0..4 (k even) or 5..9 (k odd)
         const double v = -2.2 + 4.4 * ((k * 2654435761u) % 100003) / 100003.0;
-        args[k] = (float)v * (float)(1 << (k % 10));
+        args[k] = (float)v;
     }
     std::vector<uint32_t> pat(512);
     for (int k = 0; k < 512; ++k) pat[k] = 0x9e3779b9u * (k + 1);
     float *d1, *d2, *sub, *dargs, *sc, *ex; uint32_t *dpat, *dlds, *dlds2;
     ST_CHK(hipMalloc(&d1, 4096)); ST_CHK(hipMalloc(&d2, 4096)); ST_CHK(hipMalloc(&sub, 16));
-    ST_CHK(hipMalloc(&dargs, n * 4)); ST_CHK(hipMalloc(&sc, n * 8)); ST_CHK(hipMalloc(&ex, n * 4));
+    ST_CHK(hipMalloc(&dargs, n * 4)); ST_CHK(hipMalloc(&sc, n * 40)); ST_CHK(hipMalloc(&ex, n * 4));
     ST_CHK(hipMalloc(&dpat, 2048)); ST_CHK(hipMalloc(&dlds, 2048)); ST_CHK(hipMalloc(&dlds2, 2048));
     ST_CHK(hipMemcpy(dargs, args.data(), n * 4, hipMemcpyHostToDevice));
     ST_CHK(hipMemcpy(dpat, pat.data(), 2048, hipMemcpyHostToDevice));
     hipLaunchKernelGGL(selftest_kernel, dim3(1), dim3(256), 0, stream, d1, d2, sub, dpat, dlds, dargs, sc, ex, n, dlds2);
     ST_CHK(hipGetLastError());
     ST_CHK(hipStreamSynchronize(stream));
-    std::vector<float> h1(1024), h2(1024), hsc(2 * n), hex(n); float hsub = -1.f; std::vector<uint32_t> hl(512), hl2(512);
+    std::vector<float> h1(1024), h2(1024), hsc(10 * n), hex(n); float hsub = -1.f; std::vector<uint32_t> hl(512), hl2(512);
     ST_CHK(hipMemcpy(h1.data(), d1, 4096, hipMemcpyDeviceToHost));
     ST_CHK(hipMemcpy(h2.data(), d2, 4096, hipMemcpyDeviceToHost));
     ST_CHK(hipMemcpy(&hsub, sub, 4, hipMemcpyDeviceToHost));
     ST_CHK(hipMemcpy(hl.data(), dlds, 2048, hipMemcpyDeviceToHost));
     ST_CHK(hipMemcpy(hl2.data(), dlds2, 2048, hipMemcpyDeviceToHost));
-    ST_CHK(hipMemcpy(hsc.data(), sc, n * 8, hipMemcpyDeviceToHost));
+    ST_CHK(hipMemcpy(hsc.data(), sc, n * 40, hipMemcpyDeviceToHost));
     ST_CHK(hipMemcpy(hex.data(), ex, n * 4, hipMemcpyDeviceToHost));
     for (void* p : {(void*)d1, (void*)d2, (void*)sub, (void*)dargs, (void*)sc, (void*)ex, (void*)dpat, (void*)dlds, (void*)dlds2}) (void)hipFree(p);
 
@@ -133,8 +134,11 @@ int run_selftest(int32_t* rep, hipStream_t stream) {
     for (int k = 0; k < 512; ++k) if (hl2[k] != pat[k]) rep[6]++;
     double worst = 0.0, worst_e = 0.0;
     for (int k = 0; k < n; ++k) {
-        worst = std::fmax(worst, std::fabs((double)hsc[2 * k] - std::sin((double)args[k])));
-        worst = std::fmax(worst, std::fabs((double)hsc[2 * k + 1] - std::cos((double)args[k])));
+        for (int b = 0; b < 5; ++b) {
+            const double a = (double)(args[k] * (float)(1 << (b + ((k & 1) ? 5 : 0))));   // the fp32 product the reference forms
+            worst = std::fmax(worst, std::fabs((double)hsc[10 * k + 2 * b] - std::sin(a)));
+            worst = std::fmax(worst, std::fabs((double)hsc[10 * k + 2 * b + 1] - std::cos(a)));
+        }
         const double x = (double)(-20.f + 40.f * (float)k / (float)n);
         worst_e = std::fmax(worst_e, std::fabs((double)hex[k] - std::exp(x)) / std::exp(x));
     }

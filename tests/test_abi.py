@@ -85,3 +85,29 @@ def test_stream_layout_properties():
     assert (np.abs(nz) >= 2.0 ** -14).mean() > 0.99                            # lo halves are fp16-normal
     # head tiles: rows 4..7 repeat rows 0..3 so that both lane halves see the outputs
     assert np.array_equal(bias[-1][:3], sd["_rgb_linear.bias"]) and np.array_equal(bias[-1][4:7], sd["_rgb_linear.bias"])
+
+
+def test_kernel_owns_m0(tmp_path):
+    """nwe_kernel_mfma.hip keeps the LDS-DMA destination in M0 across statements (one write per group of four pieces),
+    which is sound only while hipcc emits no M0 use of its own in that kernel: disassemble the SHIPPED library and check
+    that every instruction touching m0 in the render kernels' code object is one of ours (s_mov_b32 m0, <scalar register>)."""
+    import shutil
+    import subprocess
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump):
+        pytest.skip("llvm-objdump not available")
+    lib = tmp_path / "libnwe_hip.so"
+    shutil.copy(_lib.LIB_PATH, lib)
+    subprocess.run([objdump, "--offloading", lib.name], cwd=tmp_path, check=True, capture_output=True)
+    checked = 0
+    for co in sorted(tmp_path.glob("*.hipv4-amdgcn-amd-amdhsa--gfx950")):
+        dis = subprocess.run([objdump, "-d", co.name], cwd=tmp_path, check=True, capture_output=True, text=True).stdout
+        if "render_mfma_kernel" not in dis:
+            continue
+        body = dis[dis.index("render_mfma_kernel"):]
+        for line in body.splitlines():
+            ins = line.split("//")[0].strip()
+            if re.search(r"\bm0\b", ins):
+                assert re.fullmatch(r"s_mov_b32 m0, (s\d+|vcc_lo|vcc_hi)", ins), f"unexpected M0 use in the MFMA kernel: {ins!r}"
+                checked += 1
+    assert checked > 0, "no LDS-DMA destination writes found: is this the right code object?"

@@ -59,7 +59,7 @@ def test_selftest_hardware_assumptions(r_c1):
     assert rep[1] == 0, "accumulator-as-B-operand k permutation differs from hidden_col()"
     assert rep[3] == 0, "LDS-DMA lane order differs"
     assert rc == 0
-    assert rep[4] < 500, f"sincosf error {rep[4]}e-9 too large for the top encoding band"
+    assert rep[4] < 100, f"octave_sincos error {rep[4]}e-9: the positional encoding must be fp32-rounding accurate in every band"
     assert rep[5] < 500, f"expf relative error {rep[5]}e-9"
 
 

@@ -8,6 +8,7 @@ i=0
 while read -r line; do
   [ -z "$line" ] && continue
   i=$((i+1))
+  if [ -n "$PASSES" ] && ! echo " $PASSES " | grep -q " $i "; then continue; fi
   rocprofv3 --pmc $line -d $ROOT/gpurun_out/pmc_$i -o x --output-format csv -- python3 $ROOT/tools/prof_run.py > $ROOT/gpurun_out/pmc_$i.log 2>&1
   echo "pass $i done: $line"
 done <<'LIST'

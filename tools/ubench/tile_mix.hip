@@ -11,7 +11,7 @@ typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef float f16v __attribute__((ext_vector_type(16)));
 constexpr int KSTEPS = 16, TILES = 1000, LDS_BYTES = 140 * 1024;
 
-template <int RD, int DG, bool BARRIER, int V0, int V1, int V2>
+template <int RD, int DG, bool BARRIER, int V0, int V1, int V2, int FK = 0, bool BAGPR = false>
 __global__ __launch_bounds__(256, 1) void k(float* out, const h8* src, unsigned long long* cyc) {
     extern __shared__ char lds[];
     const int lane = threadIdx.x & 63;
@@ -19,6 +19,7 @@ __global__ __launch_bounds__(256, 1) void k(float* out, const h8* src, unsigned 
     for (int i = threadIdx.x; i < LDS_BYTES / 16; i += 256) reinterpret_cast<h8*>(lds)[i] = src[i & 1023];
     __syncthreads();
     h8 xh = src[lane], xl = src[lane + 64];
+    if (BAGPR) asm volatile("" : "+a"(xh), "+a"(xl));
     h8 fh[4], fl[4];
     for (int i = 0; i < 4; ++i) { fh[i] = src[lane + 128 + 64 * i]; fl[i] = src[lane + 384 + 64 * i]; }
     f16v acc;
@@ -48,7 +49,14 @@ __global__ __launch_bounds__(256, 1) void k(float* out, const h8* src, unsigned 
                 if (m == (RD == 0 ? 0 : RD)) fl[slot] = *reinterpret_cast<const h8*>(cb + (2 * q + 1) * 1024);
                 const int nv = (dma_k && m == DG) ? 0 : (m == 0 ? V0 : (m == 1 ? V1 : V2));
 #pragma unroll
-                for (int i = 0; i < nv; ++i) asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(va[i & 7]) : "v"(va[(i + 1) & 7]));
+                for (int i = 0; i < nv; ++i) {
+                    if (FK == 0) asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(va[i & 7]) : "v"(va[(i + 1) & 7]));
+                    if (FK == 1) asm volatile("v_accvgpr_read_b32 %0, a200" : "=v"(va[i & 7]));
+                    if (FK == 2) asm volatile("v_accvgpr_write_b32 a201, %0" :: "v"(va[i & 7]));
+                    if (FK == 3) asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(va[i & 7]) : "v"(va[(i + 1) & 7]), "v"(va[(i + 2) & 7]));
+                    if (FK == 4) asm volatile("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(va[i & 7]) : "v"(va[(i + 1) & 7]), "v"(va[(i + 2) & 7]));
+                    if (FK == 5) asm volatile("v_max_f32 %0, %1, %2" : "=v"(va[i & 7]) : "v"(va[(i + 1) & 7]), "v"(va[(i + 2) & 7]));
+                }
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -64,14 +72,14 @@ __global__ __launch_bounds__(256, 1) void k(float* out, const h8* src, unsigned 
     if (lane == 0) cyc[blockIdx.x * 4 + wave] = t1 - t0;
 }
 
-template <int RD, int DG, bool BARRIER, int V0, int V1, int V2>
+template <int RD, int DG, bool BARRIER, int V0, int V1, int V2, int FK = 0, bool BAGPR = false>
 void run(float* out, h8* src, unsigned long long* cyc, int nblk) {
-    auto fn = k<RD, DG, BARRIER, V0, V1, V2>;
+    auto fn = k<RD, DG, BARRIER, V0, V1, V2, FK, BAGPR>;
     (void)hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     for (int rep = 0; rep < 2; ++rep) { fn<<<nblk, 256, LDS_BYTES>>>(out, src, cyc); (void)hipDeviceSynchronize(); }
     unsigned long long c[4];
     (void)hipMemcpy(c, cyc, sizeof(c), hipMemcpyDeviceToHost);
-    printf("reads %d  dma gap %2d  barrier %d  valu %d,%d,%d : %7.1f cycles/tile  (x%.3f)  %s\n", RD, DG, (int)BARRIER, V0, V1, V2,
+    printf("reads %d  dma gap %2d  barrier %d  valu %d,%d,%d kind %d Bagpr %d: %7.1f cycles/tile  (x%.3f)  %s\n", RD, DG, (int)BARRIER, V0, V1, V2, FK, (int)BAGPR,
            (double)c[0] / TILES, (double)c[0] / TILES / 1536.0, hipGetErrorString(hipGetLastError()));
 }
 
@@ -82,21 +90,18 @@ int main() {
     (void)hipMemset(src, 0, 1024 * 16);
 #define R(...) run<__VA_ARGS__>(out, src, cyc, nblk)
     R(0, -1, false, 0, 0, 0);
-    R(0, -1, true, 0, 0, 0);
-    R(0, 0, true, 0, 3, 3);
-    R(0, 1, true, 0, 3, 3);
-    R(0, 2, true, 0, 3, 3);
-    R(0, 1, true, 2, 2, 2);
-    R(0, 2, true, 2, 2, 2);
-    R(1, 2, true, 2, 2, 2);
-    R(1, 2, true, 0, 3, 3);
-    R(2, 1, true, 2, 2, 2);
-    R(1, 2, true, 3, 3, 3);
-    R(1, 2, false, 3, 3, 3);
-    R(0, 2, true, 0, 4, 4);
-    R(1, 2, true, 2, 3, 3);
-    R(0, 2, false, 0, 4, 4);
-    R(0, 2, true, 0, 2, 2);
-    R(0, 2, true, 0, 1, 1);
+    R(0, -1, false, 4, 4, 4, 0, false);
+    R(0, -1, false, 4, 4, 4, 0, true);
+    R(0, -1, false, 4, 4, 4, 1, false);
+    R(0, -1, false, 4, 4, 4, 1, true);
+    R(0, -1, false, 4, 4, 4, 2, false);
+    R(0, -1, false, 4, 4, 4, 2, true);
+    R(0, -1, false, 4, 4, 4, 3, false);
+    R(0, -1, false, 4, 4, 4, 3, true);
+    R(0, -1, false, 4, 4, 4, 4, true);
+    R(0, -1, false, 4, 4, 4, 5, true);
+    R(0, 1, true, 4, 4, 4, 0, true);
+    R(0, 1, true, 4, 4, 4, 1, true);
+    R(0, 1, true, 4, 4, 4, 3, true);
     return 0;
 }
