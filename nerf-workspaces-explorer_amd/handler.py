@@ -80,6 +80,7 @@ class NeRFReplicaInferenceHandler:
             raise NotImplementedError("endpoint_feat=True is not supported (False in every reference config)")
         self._fx, self._fy, self._cx, self._cy = pinhole_intrinsics(self._img_h, self._img_w)
         self._renderer: Optional[Renderer] = None
+        self._stage: Optional[torch.Tensor] = None   # pinned uint8 [H,W,3] staging buffer for render_coordinates
 
     # ------------------------------------------------------------------------------------------------
     def set_sampling(self, n_samples: int, n_importance: int) -> None:
@@ -146,15 +147,37 @@ class NeRFReplicaInferenceHandler:
                 out[k] = v.reshape((poses.shape[0], r1 - r0, W) + tuple(v.shape[1:]))
         return out
 
-    def render_coordinates(self, init_coordinates: COORD, coordinates: COORD) -> np.ndarray:
+    def render_coordinates(self, init_coordinates: COORD, coordinates: COORD, *, out: Optional[np.ndarray] = None,
+                           preview: bool = False) -> np.ndarray:
         """handler.py:166-185: uint8 [H,W,3], C-contiguous (Qt wraps ``image.data`` with stride 3*W,
-        application/app.py:339-340)."""
+        application/app.py:339-340).
+
+        Frame hand-off: ``to8b`` (model_utils.py:9, truncating) runs on the device, the 3 bytes/pixel image goes through
+        a pinned staging buffer kept by the handler, and lands either in a fresh array (the reference's behaviour) or in
+        ``out``, a caller-owned uint8 [H,W,3] array such as the one a GUI image wraps.  ``preview=True`` renders the coarse
+        pass only (Ns samples through the coarse net, a quarter of the work) for a fast first image."""
+        r = self._need_renderer()
         camera_pose = get_camera_poses_from_list_of_coordinates(init_coordinates, [coordinates])   # :170
-        res = self.render_batch(camera_pose.numpy(), self._img_h, self._img_w, outputs=("rgb",))
-        img = self._need_renderer().to8b(res["rgb"][0])                                             # :183
-        host = np.ascontiguousarray(img.cpu().numpy().reshape(self._img_h, self._img_w, 3))
+        H, W = self._img_h, self._img_w
+        if out is not None and (out.dtype != np.uint8 or out.shape != (H, W, 3) or not out.flags.c_contiguous):
+            raise ValueError(f"out must be a C-contiguous uint8 array of shape {(H, W, 3)}")
+        if preview and self._n_importance > 0:
+            r.set_sampling(self._n_samples, 0)
+        try:
+            res = self.render_batch(camera_pose.numpy(), H, W, outputs=("rgb",))
+        finally:
+            if preview and self._n_importance > 0:
+                r.set_sampling(self._n_samples, self._n_importance)
+        img = r.to8b(res["rgb"][0])                                                                 # :183
+        if self._stage is None or tuple(self._stage.shape) != (H, W, 3):
+            self._stage = torch.empty((H, W, 3), dtype=torch.uint8, pin_memory=True)
+        self._stage.copy_(img.reshape(H, W, 3), non_blocking=True)
+        torch.cuda.current_stream(img.device).synchronize()
         self._report_flags(res["flags"])
-        return host
+        if out is None:
+            return self._stage.numpy().copy()
+        np.copyto(out, self._stage.numpy())
+        return out
 
     def _render_rays(self, flat_rays: torch.Tensor, outputs: Optional[Sequence[str]] = None,
                      precision: Optional[str] = None) -> Dict[str, torch.Tensor]:

@@ -416,3 +416,29 @@ def test_handler_drop_in_surface():
     assert np.abs(img.reshape(-1, 3)[idx.numpy()].astype(int) - ref8)[~cliff].max() <= 1
     d = h._render_rays(rays[idx].contiguous().cuda())
     assert set(d) >= {"rgb_fine", "disp_fine", "acc_fine", "depth_fine", "rgb_coarse", "z_std"}
+
+
+@pytest.mark.gpu
+def test_frame_hand_off_and_preview():
+    """render_coordinates writes the truncated uint8 frame (model_utils.py:9) into a caller-owned buffer
+    through the pinned staging copy, bit-identical to the fresh-array path; preview=True is the coarse composition
+    (handler.py:226-234) and leaves the handler's sampling unchanged."""
+    h = nwe_amd.NeRFReplicaInferenceHandler("office_tokyo", "/nonexistent/model.ckpt")
+    sd_c, sd_f = nwe_amd.synthetic.thin_fog(_sd(1000, 8, 256)), _sd(1001, 8, 256)
+    h.initialize_models(state_dicts=(sd_c, sd_f))
+    init = nwe_amd.COORD(x=0.0, y=-0.5, z=-0.76, yaw=0.0, pitch=-90.0, roll=0.0)
+    turn = nwe_amd.COORD(yaw=-60.0)
+    fresh = h.render_coordinates(init, turn)
+    buf = np.zeros((240, 320, 3), np.uint8)
+    ret = h.render_coordinates(init, turn, out=buf)
+    assert ret is buf and np.array_equal(buf, fresh)
+    again = h.render_coordinates(init, nwe_amd.COORD(yaw=0.0))
+    assert not np.array_equal(again, fresh) and np.array_equal(buf, fresh), "a returned frame must not alias the staging buffer"
+    with pytest.raises(ValueError):
+        h.render_coordinates(init, turn, out=np.zeros((240, 320, 4), np.uint8))
+    # preview = coarse pass only: equals rgb_coarse of the full render, and the next full render is unchanged
+    prev = h.render_coordinates(init, turn, preview=True)
+    pose = nwe_amd.get_camera_poses_from_list_of_coordinates(init, [turn])[0].numpy()
+    full = h.render(pose, outputs=("rgb", "rgb_coarse"))
+    assert np.array_equal(prev, O.to8b(full["rgb_coarse"].cpu().numpy()))
+    assert np.array_equal(h.render_coordinates(init, turn), fresh)
