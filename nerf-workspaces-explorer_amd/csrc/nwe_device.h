@@ -96,25 +96,35 @@ struct Composite {
     __device__ __forceinline__ void reset() {
         t_run = 1.0; r = g = b = depth = acc = 0.f;
     }
-    // raw = network output for this sample, z = its depth, z_next = next depth (ignored when last).
-    // Returns the sample's weight (alpha * transmittance).
-    __device__ __forceinline__ float step(float raw_r, float raw_g, float raw_b, float raw_s, float z, float z_next,
-                                          bool last, float dnorm) {
+    // The per-sample half that needs no running state (model_utils.py:49-62): opacity and colour of one sample from the
+    // network output, its depth and the next depth (ignored when last).
+    static __device__ __forceinline__ float4 shade(float raw_r, float raw_g, float raw_b, float raw_s, float z, float z_next,
+                                                   bool last, float dnorm) {
         float dist = last ? 1e10f : __fsub_rn(z_next, z);                    // :51-56
         dist = __fmul_rn(dist, dnorm);                                       // :60
         const float sig = fmaxf(raw_s, 0.f);                                 // relu, :49
         const float alpha = __fsub_rn(1.f, expf(-__fmul_rn(sig, dist)));     // :49
-        const float w = __fmul_rn(alpha, (float)t_run);                      // :79-80 (cumprod shifted by one)
-        t_run *= (double)__fadd_rn(__fsub_rn(1.f, alpha), 1e-10f);
         const float cr = __fdiv_rn(1.f, __fadd_rn(1.f, expf(-raw_r)));       // sigmoid, :62
         const float cg = __fdiv_rn(1.f, __fadd_rn(1.f, expf(-raw_g)));
         const float cb = __fdiv_rn(1.f, __fadd_rn(1.f, expf(-raw_b)));
-        r = __fadd_rn(r, __fmul_rn(w, cr));                                  // :84
-        g = __fadd_rn(g, __fmul_rn(w, cg));
-        b = __fadd_rn(b, __fmul_rn(w, cb));
+        return make_float4(cr, cg, cb, alpha);
+    }
+    // The sequential half (:79-95), in sample order: returns the sample's weight (alpha * transmittance).
+    __device__ __forceinline__ float accumulate(float4 ca, float z) {
+        const float alpha = ca.w;
+        const float w = __fmul_rn(alpha, (float)t_run);                      // :79-80 (cumprod shifted by one)
+        t_run *= (double)__fadd_rn(__fsub_rn(1.f, alpha), 1e-10f);
+        r = __fadd_rn(r, __fmul_rn(w, ca.x));                                // :84
+        g = __fadd_rn(g, __fmul_rn(w, ca.y));
+        b = __fadd_rn(b, __fmul_rn(w, ca.z));
         depth = __fadd_rn(depth, __fmul_rn(w, z));                           // :93
         acc = __fadd_rn(acc, w);                                             // :95
         return w;
+    }
+    // raw = network output for this sample, z = its depth, z_next = next depth (ignored when last).
+    __device__ __forceinline__ float step(float raw_r, float raw_g, float raw_b, float raw_s, float z, float z_next,
+                                          bool last, float dnorm) {
+        return accumulate(shade(raw_r, raw_g, raw_b, raw_s, z, z_next, last, dnorm), z);
     }
     // :94  1 / max(1e-10, depth/acc); torch.max propagates NaN (acc == 0 -> NaN)
     __device__ __forceinline__ float disp() const {

@@ -667,11 +667,19 @@ struct Smem {
     static constexpr int BIAS_BYTES = ((S::N_CHUNKS * 32 * 4 + 255) / 256) * 256;
     static constexpr int WOFF = BOFF + 2 * BIAS_BYTES;                               // per-wave coarse weights / cdf
     static constexpr int TOFF = WOFF + kWaves * kMfmaMaxSamples * kRaysPerWave * 4;  // t, 1-t, u tables
-    static constexpr int TOTAL = TOFF + (2 * kMfmaMaxSamples + kMaxImportance) * 4;
-    static_assert(TOTAL <= 160 * 1024, "LDS budget");
+    static constexpr int XOFF = TOFF + (2 * kMfmaMaxSamples + kMaxImportance) * 4;     // sample-split mode: shaded samples, 2 buffers
+    static constexpr int TOTAL = XOFF + 2 * kWaves * kRaysPerWave * 16;
+    static_assert(XOFF % 16 == 0 && TOTAL <= 160 * 1024, "LDS budget");
 };
 
-template <int W, int D, int SKIP, bool X3>
+// Two work decompositions, same arithmetic in the same order (results are bit-identical):
+//   SPLIT = false: the four waves of a workgroup own four ray packets (128 rays) and walk all their samples;
+//   SPLIT = true:  the workgroup owns ONE packet (32 rays); wave w evaluates samples 4i + w, the shaded samples (colour,
+//                  opacity) are exchanged through LDS and every wave runs the sequential compositing / importance
+//                  sampling for all samples (a few dozen VALU ops per sample, redundantly).  The scheduling unit is a
+//                  quarter of the rays and a quarter of the iterations: a 320x240 frame fills the last round of
+//                  workgroups 17 % better, a 64x64 frame runs 3x faster; launch_t() picks per launch.
+template <int W, int D, int SKIP, bool X3, bool SPLIT>
 __global__ void __launch_bounds__(256) render_mfma_kernel(RenderArgs a, NetMfma nc, NetMfma nf) {
     using S = Shape<W, D>;
     using SM = Smem<W, D>;
@@ -693,8 +701,10 @@ __global__ void __launch_bounds__(256) render_mfma_kernel(RenderArgs a, NetMfma 
         if (ni > 0) s_bias[SM::BIAS_BYTES / 4 + i] = nf.bias[i];
     }
 
-    const int64_t ridx = ((int64_t)blockIdx.x * kWaves + wave) * kRaysPerWave + (lane & 31);
-    const bool live = ridx < a.n_rays && half == 0;
+    const int64_t packet = SPLIT ? (int64_t)blockIdx.x : (int64_t)blockIdx.x * kWaves + wave;
+    const int64_t ridx = packet * kRaysPerWave + (lane & 31);
+    const bool lane_live = ridx < a.n_rays && half == 0;      // this lane stores per-sample outputs of its ray
+    const bool live = lane_live && (!SPLIT || wave == 0);      // ... and the per-ray results (every wave holds them in SPLIT mode)
     const int64_t rclamp = ridx < a.n_rays ? ridx : a.n_rays - 1;
     const Ray ray = load_ray(a, rclamp);
 
@@ -722,67 +732,165 @@ __global__ void __launch_bounds__(256) render_mfma_kernel(RenderArgs a, NetMfma 
         const float* bias = s_bias + (pass == 0 ? 0 : SM::BIAS_BYTES / 4);
         const int Stot = pass == 0 ? ns : ns + ni;
         comp.reset();
-        float z_cur, z_next = 0.f;
-        if (pass == 0) z_cur = coarse_z(ray, s_t[0], s_omt[0]);
-        else {
-            fs.prepare(ray);
-            z_cur = a.z_fine_in ? a.z_fine_in[rclamp * Stot] : fs.next(ray);
-        }
-        for (int s = 0; s < Stot; ++s) {
-#ifdef NWE_STAMPS
-            const unsigned long long t0 = __builtin_amdgcn_s_memtime();
-#endif
-            // chunks 0 and 1 (layer 0, tiles 0 and 1) fly while the sample's depth and gamma(x) are computed
-            wk.start(net.stream, bias);
-            wk.begin(S::N_L0, 0);
+        if constexpr (SPLIT) {
+            // depths are produced strictly in order: zq[0..3] = this iteration's four samples, zq[4] = the first of the next
+            int produced = 0;
+            auto gen = [&]() -> float {
+                const int i = produced++;
+                if (i >= Stot) return 0.f;
+                if (pass == 0) return coarse_z(ray, s_t[i], s_omt[i]);
+                return a.z_fine_in ? a.z_fine_in[rclamp * Stot + i] : fs.next(ray);
+            };
+            if (pass == 1) fs.prepare(ray);
+            float zq[5], zp[4];
 #pragma unroll
-            for (int i = 0; i < S::N_L0; ++i) wk.piece(i);
-            wk.begin(S::N_L0, 1);
+            for (int k = 0; k < 5; ++k) zq[k] = gen();
+            float4* xch = reinterpret_cast<float4*>(smem + SM::XOFF);
+            const int n_it = (Stot + 3) / 4;
+            // composite the (up to four) samples of iteration `it`, shaded by the four waves, in sample order
+            auto drain = [&](int it) {
+                const float4* x = xch + (it & 1) * (kWaves * kRaysPerWave) + (lane & 31);
 #pragma unroll
-            for (int i = 0; i < S::N_L0; ++i) wk.piece(i);
-            if (s + 1 < Stot) {
-                if (pass == 0) z_next = coarse_z(ray, s_t[s + 1], s_omt[s + 1]);
-                else z_next = a.z_fine_in ? a.z_fine_in[rclamp * Stot + s + 1] : fs.next(ray);
-            }
-            float px, py, pz;
-            point_at(ray, z_cur, px, py, pz);
-            h8 Ghi[S::KG], Glo[S::KG];
-            // handler.py:93: scalar_factor = 10, a true division (embedding.py:48)
-            encode<5, S::KG, X3>(__fdiv_rn(px, 10.f), __fdiv_rn(py, 10.f), __fdiv_rn(pz, 10.f), half, Ghi, Glo);
-#ifdef NWE_STAMPS
-            const unsigned long long t1 = __builtin_amdgcn_s_memtime();
-#endif
-            wk.template sync<false>();
-            Frags F;
-#pragma unroll
-            for (int k = 0; k < PD; ++k) {
-                F.hi[k] = *reinterpret_cast<const h8*>(wk.cur() + lane * 16 + (2 * k) * kTileBytes);
-                if (X3) F.lo[k] = *reinterpret_cast<const h8*>(wk.cur() + lane * 16 + (2 * k + 1) * kTileBytes);
-            }
-#ifdef NWE_STAMPS
-            const unsigned long long t2 = __builtin_amdgcn_s_memtime();
-            wk.st_t0 = t2;
-#endif
-            float rr, rg, rb, rs;
-            mlp_eval<W, D, SKIP, X3>(wk, F, lane, net.inv_scale, Ghi, Glo, GDhi, GDlo, rr, rg, rb, rs);
-#ifdef NWE_STAMPS
-            const unsigned long long t3 = __builtin_amdgcn_s_memtime();
-#endif
-            const float w = comp.step(rr, rg, rb, rs, z_cur, z_next, s + 1 == Stot, ray.dnorm);
-            if (pass == 0) fs.wc[s * kRaysPerWave] = w;
-            if (live) {
-                float* raw = pass == 0 ? a.out.raw_coarse : a.out.raw_fine;
-                if (raw) {
-                    *reinterpret_cast<float4*>(raw + (ridx * Stot + s) * 4) = make_float4(rr, rg, rb, rs);
-                    if (bad(rr) || bad(rg) || bad(rb) || bad(rs)) flags |= NWE_FLAG_RAW;
+                for (int k = 0; k < 4; ++k) {
+                    const int si = 4 * it + k;
+                    if (si < Stot) {
+                        const float w = comp.accumulate(x[k * kRaysPerWave], zp[k]);
+                        if (pass == 0) fs.wc[si * kRaysPerWave] = w;
+                    }
                 }
-                if (pass == 1 && a.out.z_fine) a.out.z_fine[ridx * Stot + s] = z_cur;
-            }
-            z_cur = z_next;
+            };
+            for (int it = 0; it < n_it; ++it) {
 #ifdef NWE_STAMPS
-            const unsigned long long t4 = __builtin_amdgcn_s_memtime();
-            st_enc += t1 - t0; st_sync += t2 - t1; st_mlp += t3 - t2; st_comp += t4 - t3;
+                const unsigned long long t0 = __builtin_amdgcn_s_memtime();
 #endif
+                wk.start(net.stream, bias);
+                wk.begin(S::N_L0, 0);
+#pragma unroll
+                for (int i = 0; i < S::N_L0; ++i) wk.piece(i);
+                wk.begin(S::N_L0, 1);
+#pragma unroll
+                for (int i = 0; i < S::N_L0; ++i) wk.piece(i);
+                const int s_own = 4 * it + wave;
+                const bool own_valid = s_own < Stot;
+                float z_own = zq[0], z_nxt = zq[1];
+                if (wave == 1) { z_own = zq[1]; z_nxt = zq[2]; }
+                if (wave == 2) { z_own = zq[2]; z_nxt = zq[3]; }
+                if (wave == 3) { z_own = zq[3]; z_nxt = zq[4]; }
+                float nz[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) nz[k] = gen();
+                float px, py, pz;
+                point_at(ray, z_own, px, py, pz);
+                h8 Ghi[S::KG], Glo[S::KG];
+                encode<5, S::KG, X3>(__fdiv_rn(px, 10.f), __fdiv_rn(py, 10.f), __fdiv_rn(pz, 10.f), half, Ghi, Glo);
+#ifdef NWE_STAMPS
+                const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+#endif
+                wk.template sync<false>();   // also publishes the previous iteration's shaded samples
+                Frags F;
+#pragma unroll
+                for (int k = 0; k < PD; ++k) {
+                    F.hi[k] = *reinterpret_cast<const h8*>(wk.cur() + lane * 16 + (2 * k) * kTileBytes);
+                    if (X3) F.lo[k] = *reinterpret_cast<const h8*>(wk.cur() + lane * 16 + (2 * k + 1) * kTileBytes);
+                }
+                if (it > 0) drain(it - 1);   // behind the fragment reads, whose latency it covers
+#pragma unroll
+                for (int k = 0; k < 4; ++k) zp[k] = zq[k];
+#ifdef NWE_STAMPS
+                const unsigned long long t2 = __builtin_amdgcn_s_memtime();
+                wk.st_t0 = t2;
+#endif
+                float rr, rg, rb, rs;
+                mlp_eval<W, D, SKIP, X3>(wk, F, lane, net.inv_scale, Ghi, Glo, GDhi, GDlo, rr, rg, rb, rs);
+#ifdef NWE_STAMPS
+                const unsigned long long t3 = __builtin_amdgcn_s_memtime();
+#endif
+                if (own_valid) {
+                    xch[(it & 1) * (kWaves * kRaysPerWave) + wave * kRaysPerWave + (lane & 31)] =
+                        Composite::shade(rr, rg, rb, rs, z_own, z_nxt, s_own + 1 == Stot, ray.dnorm);
+                    if (lane_live) {
+                        float* raw = pass == 0 ? a.out.raw_coarse : a.out.raw_fine;
+                        if (raw) {
+                            *reinterpret_cast<float4*>(raw + (ridx * Stot + s_own) * 4) = make_float4(rr, rg, rb, rs);
+                            if (bad(rr) || bad(rg) || bad(rb) || bad(rs)) flags |= NWE_FLAG_RAW;
+                        }
+                        if (pass == 1 && a.out.z_fine) a.out.z_fine[ridx * Stot + s_own] = z_own;
+                    }
+                }
+                zq[0] = zq[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) zq[k + 1] = nz[k];
+#ifdef NWE_STAMPS
+                const unsigned long long t4 = __builtin_amdgcn_s_memtime();
+                st_enc += t1 - t0; st_sync += t2 - t1; st_mlp += t3 - t2; st_comp += t4 - t3;
+#endif
+            }
+            __syncthreads();
+            drain(n_it - 1);
+            __syncthreads();   // the exchange buffers are free again for the next pass
+        } else {
+            float z_cur, z_next = 0.f;
+            if (pass == 0) z_cur = coarse_z(ray, s_t[0], s_omt[0]);
+            else {
+                fs.prepare(ray);
+                z_cur = a.z_fine_in ? a.z_fine_in[rclamp * Stot] : fs.next(ray);
+            }
+            for (int s = 0; s < Stot; ++s) {
+    #ifdef NWE_STAMPS
+                const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    #endif
+                // chunks 0 and 1 (layer 0, tiles 0 and 1) fly while the sample's depth and gamma(x) are computed
+                wk.start(net.stream, bias);
+                wk.begin(S::N_L0, 0);
+    #pragma unroll
+                for (int i = 0; i < S::N_L0; ++i) wk.piece(i);
+                wk.begin(S::N_L0, 1);
+    #pragma unroll
+                for (int i = 0; i < S::N_L0; ++i) wk.piece(i);
+                if (s + 1 < Stot) {
+                    if (pass == 0) z_next = coarse_z(ray, s_t[s + 1], s_omt[s + 1]);
+                    else z_next = a.z_fine_in ? a.z_fine_in[rclamp * Stot + s + 1] : fs.next(ray);
+                }
+                float px, py, pz;
+                point_at(ray, z_cur, px, py, pz);
+                h8 Ghi[S::KG], Glo[S::KG];
+                // handler.py:93: scalar_factor = 10, a true division (embedding.py:48)
+                encode<5, S::KG, X3>(__fdiv_rn(px, 10.f), __fdiv_rn(py, 10.f), __fdiv_rn(pz, 10.f), half, Ghi, Glo);
+    #ifdef NWE_STAMPS
+                const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    #endif
+                wk.template sync<false>();
+                Frags F;
+    #pragma unroll
+                for (int k = 0; k < PD; ++k) {
+                    F.hi[k] = *reinterpret_cast<const h8*>(wk.cur() + lane * 16 + (2 * k) * kTileBytes);
+                    if (X3) F.lo[k] = *reinterpret_cast<const h8*>(wk.cur() + lane * 16 + (2 * k + 1) * kTileBytes);
+                }
+    #ifdef NWE_STAMPS
+                const unsigned long long t2 = __builtin_amdgcn_s_memtime();
+                wk.st_t0 = t2;
+    #endif
+                float rr, rg, rb, rs;
+                mlp_eval<W, D, SKIP, X3>(wk, F, lane, net.inv_scale, Ghi, Glo, GDhi, GDlo, rr, rg, rb, rs);
+    #ifdef NWE_STAMPS
+                const unsigned long long t3 = __builtin_amdgcn_s_memtime();
+    #endif
+                const float w = comp.step(rr, rg, rb, rs, z_cur, z_next, s + 1 == Stot, ray.dnorm);
+                if (pass == 0) fs.wc[s * kRaysPerWave] = w;
+                if (lane_live) {
+                    float* raw = pass == 0 ? a.out.raw_coarse : a.out.raw_fine;
+                    if (raw) {
+                        *reinterpret_cast<float4*>(raw + (ridx * Stot + s) * 4) = make_float4(rr, rg, rb, rs);
+                        if (bad(rr) || bad(rg) || bad(rb) || bad(rs)) flags |= NWE_FLAG_RAW;
+                    }
+                    if (pass == 1 && a.out.z_fine) a.out.z_fine[ridx * Stot + s] = z_cur;
+                }
+                z_cur = z_next;
+    #ifdef NWE_STAMPS
+                const unsigned long long t4 = __builtin_amdgcn_s_memtime();
+                st_enc += t1 - t0; st_sync += t2 - t1; st_mlp += t3 - t2; st_comp += t4 - t3;
+    #endif
+            }
         }
         if (live) {
             flags |= store_ray(a.out, ridx, comp, pass == 1);
@@ -814,12 +922,26 @@ int mfma_max_samples() { return kMfmaMaxSamples; }
 
 template <int W, int D, int SKIP>
 static void launch_t(const RenderArgs& a, const NetMfma& nc, const NetMfma& nf, bool three_pass, hipStream_t stream) {
-    const int64_t rays_per_block = kWaves * kRaysPerWave;
-    const unsigned blocks = (unsigned)((a.n_rays + rays_per_block - 1) / rays_per_block);
-    if (three_pass)
-        hipLaunchKernelGGL((render_mfma_kernel<W, D, SKIP, true>), dim3(blocks), dim3(256), 0, stream, a, nc, nf);
-    else
-        hipLaunchKernelGGL((render_mfma_kernel<W, D, SKIP, false>), dim3(blocks), dim3(256), 0, stream, a, nc, nf);
+    // Pick the decomposition that needs fewer sample iterations on the busiest CU (one workgroup per CU at a time).
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (cus <= 0) cus = 256;
+    const int64_t its = a.n_samples + (a.n_importance > 0 ? a.n_samples + a.n_importance : 0);
+    const int64_t its_split = (a.n_samples + 3) / 4 + (a.n_importance > 0 ? (a.n_samples + a.n_importance + 3) / 4 : 0);
+    const int64_t wg_packet = (a.n_rays + kWaves * kRaysPerWave - 1) / (kWaves * kRaysPerWave);
+    const int64_t wg_split = (a.n_rays + kRaysPerWave - 1) / kRaysPerWave;
+    const double t_packet = (double)((wg_packet + cus - 1) / cus) * (double)its;
+    const double t_split = (double)((wg_split + cus - 1) / cus) * (double)its_split * 1.06;   // redundant sequential part + exchange (measured 5-7 %)
+    bool split = t_split < t_packet;
+    if (const char* e = getenv("NWE_SPLIT")) split = e[0] == '1';   // tests force either decomposition
+    const unsigned blocks = (unsigned)(split ? wg_split : wg_packet);
+    if (three_pass) {
+        if (split) hipLaunchKernelGGL((render_mfma_kernel<W, D, SKIP, true, true>), dim3(blocks), dim3(256), 0, stream, a, nc, nf);
+        else hipLaunchKernelGGL((render_mfma_kernel<W, D, SKIP, true, false>), dim3(blocks), dim3(256), 0, stream, a, nc, nf);
+    } else {
+        if (split) hipLaunchKernelGGL((render_mfma_kernel<W, D, SKIP, false, true>), dim3(blocks), dim3(256), 0, stream, a, nc, nf);
+        else hipLaunchKernelGGL((render_mfma_kernel<W, D, SKIP, false, false>), dim3(blocks), dim3(256), 0, stream, a, nc, nf);
+    }
 }
 
 bool launch_render_mfma(const RenderArgs& a, const NetMfma& nc, const NetMfma& nf, bool three_pass, hipStream_t stream) {

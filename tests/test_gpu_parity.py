@@ -442,3 +442,32 @@ def test_frame_hand_off_and_preview():
     full = h.render(pose, outputs=("rgb", "rgb_coarse"))
     assert np.array_equal(prev, O.to8b(full["rgb_coarse"].cpu().numpy()))
     assert np.array_equal(h.render_coordinates(init, turn), fresh)
+
+
+@pytest.mark.gpu
+def test_work_decompositions_are_bit_identical(monkeypatch):
+    """The MFMA kernel has two work decompositions (nwe_kernel_mfma.hip: four ray packets per workgroup, or one packet
+    whose samples are dealt to the four waves); the launcher picks by frame size.  Same arithmetic in the same order:
+    every output must agree bit for bit, including ragged ray counts and sample counts that are no multiple of four."""
+    cases = [(8, 256, 64, 128, 37, 53), (8, 256, 30, 17, 20, 33), (4, 128, 32, 0, 64, 64), (4, 128, 21, 10, 9, 11)]
+    names = ("rgb", "depth", "acc", "disp", "z_std", "rgb_coarse", "depth_coarse", "acc_coarse", "raw_coarse", "raw_fine",
+             "z_fine", "sample_cond")
+    pose = O.camera_pose((0.0, -0.5, -0.77, 0.0, -90.0, 0.0), (0, 0, 0, -30.0, 0.0, 0.0))[0].numpy()
+    for D, Wn, ns, ni, H, W in cases:
+        r = nwe_amd.Renderer(0)
+        r.set_network(0, _sd(1000, D, Wn))
+        if ni:
+            r.set_network(1, _sd(1001, D, Wn))
+        r.set_sampling(ns, ni)
+        fx, fy, cx, cy = O.intrinsics(H, W)
+        outs = tuple(n for n in names if ni or n in ("rgb", "depth", "acc", "disp", "raw_coarse"))
+        res = {}
+        for mode in ("0", "1"):
+            monkeypatch.setenv("NWE_SPLIT", mode)
+            for prec in ("f16x3", "f16x1"):
+                res[mode, prec] = r.render(pose, H, W, fx=fx, fy=fy, cx=cx, cy=cy, near=0.1, far=10.0, precision=prec, outputs=outs)
+        for prec in ("f16x3", "f16x1"):
+            for k in outs:
+                a, b = res["0", prec][k], res["1", prec][k]
+                assert torch.equal(torch.nan_to_num(a, nan=-7.0), torch.nan_to_num(b, nan=-7.0)), (D, Wn, ns, ni, prec, k)
+    monkeypatch.delenv("NWE_SPLIT")
