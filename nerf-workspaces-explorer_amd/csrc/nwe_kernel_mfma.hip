@@ -5,8 +5,9 @@
 // fine MLP, compositing.  Nothing but the per-ray results reaches HBM.
 //
 // Work decomposition:
-//   * one wavefront owns a packet of 32 rays (lane&31 = ray, both lane halves carry the ray state) and
-//     walks their samples in lock step; a 256-thread workgroup = 4 packets sharing one weight stream.
+//   * a packet = 32 rays (lane&31 = ray, both lane halves carry the ray state) whose samples are walked in
+//     lock step; a 256-thread workgroup = 4 waves sharing one weight stream, either four packets (one per
+//     wave) or one packet with its samples dealt to the four waves (render_mfma_kernel, SPLIT).
 //   * the MLP is evaluated transposed, H_out^T[feature, ray] = W[feature, k] . H_in^T[k, ray], with
 //     v_mfma_f32_32x32x16_f16: A = weight tile (from LDS), B = activations.  The 32x32 result has the
 //     ray on the lane and the features in the 16 registers, which is exactly the B-operand layout of
@@ -20,9 +21,10 @@
 //     = one 32-row tile of a layer (hi/lo tile per 16-wide k-step), issued one chunk ahead, piece by
 //     piece between the MFMAs of the current tile.
 //   * one wave per SIMD: the wave's own instruction issue is the scarce resource next to the matrix
-//     pipe, so everything around the MFMAs is kept to a handful of instructions per MFMA: the
-//     epilogue of tile t (bias, ReLU, hi/lo split) is interleaved with the MFMAs of tile t+1, LDS-DMA
-//     addressing is scalar, the A fragments are read three k-steps ahead.
+//     pipe, so everything around the MFMAs is kept to a handful of instructions per MFMA and placed
+//     statically in the gaps between them: the epilogue of tile t (bias, ReLU, hi/lo split) runs in
+//     stages between the MFMAs of tile t+1 (EpiPlan), LDS-DMA addressing is scalar and each piece has a
+//     gap of its own (DmaPlan), the A fragments are read three k-steps ahead.
 #include "nwe_host.h"
 
 namespace nwe {
@@ -71,9 +73,9 @@ __device__ __forceinline__ float pend_value(const Pend& t, int r, float inv_scal
 
 typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 
-// Epilogue of a pending tile, one ELEMENT per call so that its ~7 VALU ops per element can be spread evenly over the
-// k-steps of the next tile: v = max(acc/scale + bias, lower); every second call packs the pair: hi = fp16(v),
-// lo = fp16(v - hi).  Register r of the tile is element r&7 of the (r>>3)-th of its two output k-steps.
+// Epilogue of a pending tile: v = max(acc/scale + bias, lower), hi = fp16(v), lo = fp16(v - hi); register r of the tile
+// is element r&7 of the (r>>3)-th of its two output k-steps.  This is the FALLBACK form, one element per call (every
+// second call packs a pair), used only by tiles too short for the staged plan below (EpiPlan::STAGED == false).
 template <bool X3>
 __device__ __forceinline__ void finish_elem(const Pend& t, int e, float inv_scale, float lower, float& keep, h8& hi0, h8& lo0,
                                             h8& hi1, h8& lo1) {
@@ -348,10 +350,11 @@ struct DmaPlan {
 // One 32-row tile = NKP optional "pre" k-steps (gamma(x) of the skip layer, taken if use_g) + NKH main k-steps over
 // X + NKD "post" k-steps (gamma(d) of the view layer).  Chunk layout in that order, (hi, lo) tile pair per k-step,
 // lane-linear.  On entry the fragment ring holds this tile's first PD k-steps in slots PHASE..PHASE+PD-1; on exit
-// it holds the next tile's.  The epilogue of the PREVIOUS tile (`prev` -> y*) is spread over the main k-steps (element
-// e in k-step floor(e*(NKH-1)/16)), so a pending tile that feeds this tile's last two k-steps is ready in time.  DMA: this tile issues the pieces [PD, NB) (+2 if extraB) of chunk T+1 before its
-// barrier and, after it, pieces [0, min(PD, NA)) of chunk T+2 (NA pieces per wave, +2 if extraA; NA = 0: none).
-// HASNEXT: a tile follows in this pass (its first fragments are prefetched).
+// it holds the next tile's.  The epilogue of the PREVIOUS tile (`prev` -> y*) runs in the MFMA gaps of the main
+// k-steps by EpiPlan; FEEDS says that its outputs y* are the last two k-steps of X itself (first tile of a layer, rgb
+// head), which sets the plan's deadline.  DMA (DmaPlan): this tile issues the pieces [PD, NB) (+2 if extraB) of chunk
+// T+1 in its first k-steps and, after its barrier, pieces [0, min(PD, NA)) of chunk T+2 (NA pieces per wave, +2 if
+// extraA; NA = 0: none).  HASNEXT: a tile follows in this pass (its first fragments are prefetched).
 template <int NKP, int NKH, int NKD, int PHASE, bool X3, bool PEND, int NB, int NA, bool HASNEXT, bool FEEDS = false, class WalkerT>
 __device__ __forceinline__ void tile_mma(WalkerT& wk, Frags& F, int lane, bool use_g, bool extraB, bool extraA, const h8* Ghi,
                                          const h8* Glo, const h8* Xhi, const h8* Xlo, const h8* Dhi, const h8* Dlo, Pend& cur,
