@@ -145,6 +145,20 @@ float nwe_packed_scale(const nwe_ctx *ctx, int which);
  * reference's own depths and compare the fine pass alone. */
 int nwe_debug_set_fine_depths(nwe_ctx *ctx, const float *z_dev);
 
+/* Training-mode forward (nerf/training/nerf_replica_training_handler.py:553-580; forward only): the NEXT
+ * nwe_render_rays call uses random numbers drawn by the caller exactly where the reference calls torch.rand /
+ * torch.randn, one row per ray of that call (DEVICE pointers, each may be NULL = the inference behaviour); cleared
+ * after that call.
+ *   t_rand       [n_rays, n_samples]                stratified jitter in [0,1): z = lower + (upper - lower) * t_rand (:553-562)
+ *   noise_coarse [n_rays, n_samples]                added to sigma_raw before the ReLU, i.e. randn * raw_noise_std
+ *   noise_fine   [n_rays, n_samples + n_importance] (nerf/models/model_utils.py:64-71)
+ *   u_sorted     [n_rays, n_importance]             the uniform numbers of sample_pdf(det=False) (nerf/rays/rays.py:98),
+ *                                                   sorted ascending per ray: sample_pdf is element-wise in u and the
+ *                                                   reference sorts the union of depths afterwards (:580), so the order of
+ *                                                   u does not change any output */
+int nwe_set_train_tables(nwe_ctx *ctx, const float *t_rand_dev, const float *noise_coarse_dev, const float *noise_fine_dev,
+                         const float *u_sorted_dev);
+
 /* Device self-test of the hardware assumptions the MFMA kernel relies on (fragment layouts of
  * v_mfma_f32_32x32x16_f16, fp16 subnormal operands, LDS-DMA lane order).  report[0..7] receives
  * mismatch counts / measured values; returns NWE_OK when every assumption holds. */

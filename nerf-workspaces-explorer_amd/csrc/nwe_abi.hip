@@ -43,6 +43,7 @@ struct nwe_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
     const float* dbg_z_fine = nullptr;
+    const float *trn_t = nullptr, *trn_nc = nullptr, *trn_nf = nullptr, *trn_u = nullptr;   // nwe_set_train_tables, one call
     std::string err;
 };
 
@@ -395,12 +396,14 @@ int nwe_render_rays(nwe_ctx* c, const float* rays_dev, int64_t n_rays, int preci
     int rc = check_ready(c, out, precision);
     if (rc) return rc;
     if (n_rays < 0 || (!rays_dev && n_rays > 0)) return fail(c, NWE_ERR_INVALID, "bad rays");
-    if (n_rays == 0) { c->dbg_z_fine = nullptr; return NWE_OK; }
+    if (n_rays == 0) { c->dbg_z_fine = nullptr; c->trn_t = c->trn_nc = c->trn_nf = c->trn_u = nullptr; return NWE_OK; }
     HIPCHK(c, hipSetDevice(c->device));
     RenderArgs a = {};
     a.rays = rays_dev; a.n_rays = n_rays; a.W = 1; a.rows = 1;
     a.z_fine_in = c->dbg_z_fine;
     c->dbg_z_fine = nullptr;
+    a.t_rand = c->trn_t; a.noise_c = c->trn_nc; a.noise_f = c->trn_nf; a.u_rand = c->trn_u;
+    c->trn_t = c->trn_nc = c->trn_nf = c->trn_u = nullptr;
     a.out = *out;
     return launch(c, a, precision, stream);
 }
@@ -459,6 +462,13 @@ float nwe_packed_scale(const nwe_ctx* c, int which) {
 int nwe_debug_set_fine_depths(nwe_ctx* c, const float* z_dev) {
     if (!c) return NWE_ERR_INVALID;
     c->dbg_z_fine = z_dev;
+    return NWE_OK;
+}
+
+int nwe_set_train_tables(nwe_ctx* c, const float* t_rand_dev, const float* noise_coarse_dev, const float* noise_fine_dev,
+                         const float* u_sorted_dev) {
+    if (!c) return NWE_ERR_INVALID;
+    c->trn_t = t_rand_dev; c->trn_nc = noise_coarse_dev; c->trn_nf = noise_fine_dev; c->trn_u = u_sorted_dev;
     return NWE_OK;
 }
 

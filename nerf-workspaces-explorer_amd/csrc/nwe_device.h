@@ -31,6 +31,12 @@ struct RenderArgs {
     const float* omt_vals;
     const float* u_vals;
     const float* z_fine_in;  // test hook: fine depths [n_rays, ns+ni] instead of importance sampling
+    // training-mode forward (nerf/training/nerf_replica_training_handler.py:553-580): random numbers drawn by the host
+    // where the reference calls torch.rand / torch.randn, one row per ray of this call; each may be null (= inference)
+    const float* t_rand;     // [n_rays, ns]      stratified jitter in [0,1)                 (:560-562)
+    const float* noise_c;    // [n_rays, ns]      sigma noise, already times raw_noise_std   (model_utils.py:64-71)
+    const float* noise_f;    // [n_rays, ns+ni]
+    const float* u_rand;     // [n_rays, ni]      inverse-CDF arguments, ASCENDING per ray   (rays.py:98)
     int n_samples, n_importance;
     unsigned long long* stamps;  // diagnostic builds (-DNWE_STAMPS): per-wave cycle sums, else unused
     nwe_outputs out;
@@ -82,6 +88,23 @@ __device__ __forceinline__ float coarse_z(const Ray& r, float t, float omt) {
     return __fadd_rn(__fmul_rn(r.near, omt), __fmul_rn(r.far, t));
 }
 
+// Coarse depth i of a ray: the linspace depth (inference), or, with a row of stratified-jitter numbers, a point of the
+// interval between the mid points around it (training_handler.py:553-562): mids = .5*(z[1:] + z[:-1]),
+// upper = [mids, z[-1]], lower = [z[0], mids], z = lower + (upper - lower) * t_rand.
+struct CoarseDepths {
+    const float* t_tab; const float* omt_tab;   // LDS tables t, 1-t
+    const float* jitter;                        // this ray's t_rand row (global) or null
+    int ns;
+    __device__ __forceinline__ float base(const Ray& r, int i) const { return coarse_z(r, t_tab[i], omt_tab[i]); }
+    __device__ __forceinline__ float z(const Ray& r, int i) const {
+        const float zi = base(r, i);
+        if (!jitter) return zi;
+        const float lower = i > 0 ? __fmul_rn(.5f, __fadd_rn(zi, base(r, i - 1))) : zi;
+        const float upper = i + 1 < ns ? __fmul_rn(.5f, __fadd_rn(base(r, i + 1), zi)) : zi;
+        return __fadd_rn(lower, __fmul_rn(__fsub_rn(upper, lower), jitter[i]));
+    }
+};
+
 // handler.py:223 / :246: o + d*z, product then sum (no FMA)
 __device__ __forceinline__ void point_at(const Ray& r, float z, float& px, float& py, float& pz) {
     px = __fadd_rn(r.ox, __fmul_rn(r.dx, z));
@@ -99,10 +122,10 @@ struct Composite {
     // The per-sample half that needs no running state (model_utils.py:49-62): opacity and colour of one sample from the
     // network output, its depth and the next depth (ignored when last).
     static __device__ __forceinline__ float4 shade(float raw_r, float raw_g, float raw_b, float raw_s, float z, float z_next,
-                                                   bool last, float dnorm) {
+                                                   bool last, float dnorm, float noise = 0.f) {
         float dist = last ? 1e10f : __fsub_rn(z_next, z);                    // :51-56
         dist = __fmul_rn(dist, dnorm);                                       // :60
-        const float sig = fmaxf(raw_s, 0.f);                                 // relu, :49
+        const float sig = fmaxf(__fadd_rn(raw_s, noise), 0.f);               // relu(raw + noise), :49,:71 (noise = 0. in inference)
         const float alpha = __fsub_rn(1.f, expf(-__fmul_rn(sig, dist)));     // :49
         const float cr = __fdiv_rn(1.f, __fadd_rn(1.f, expf(-raw_r)));       // sigmoid, :62
         const float cg = __fdiv_rn(1.f, __fadd_rn(1.f, expf(-raw_g)));
@@ -123,8 +146,8 @@ struct Composite {
     }
     // raw = network output for this sample, z = its depth, z_next = next depth (ignored when last).
     __device__ __forceinline__ float step(float raw_r, float raw_g, float raw_b, float raw_s, float z, float z_next,
-                                          bool last, float dnorm) {
-        return accumulate(shade(raw_r, raw_g, raw_b, raw_s, z, z_next, last, dnorm), z);
+                                          bool last, float dnorm, float noise = 0.f) {
+        return accumulate(shade(raw_r, raw_g, raw_b, raw_s, z, z_next, last, dnorm, noise), z);
     }
     // :94  1 / max(1e-10, depth/acc); torch.max propagates NaN (acc == 0 -> NaN)
     __device__ __forceinline__ float disp() const {
@@ -141,14 +164,16 @@ struct Composite {
 // elements 0..ns-2 with the cdf (rays.py:87-90).
 struct FineSampler {
     float* wc; int stride;
-    const float* t_tab; const float* omt_tab; const float* u_tab;   // LDS tables
+    CoarseDepths cd;
+    const float* u_tab;      // LDS table of the deterministic u (rays.py:95)
+    const float* u_row;      // this ray's ascending random u (rays.py:98, global) or null
     int ns, ni;
     int ci, fj, ptr;
     float cur_f;
     double s1, s2;   // sum / sum of squares of the importance samples (z_std, handler.py:267)
     float min_denom; // smallest cdf step a sample was interpolated in (conditioning diagnostic)
 
-    __device__ __forceinline__ float zc(const Ray& r, int i) const { return coarse_z(r, t_tab[i], omt_tab[i]); }
+    __device__ __forceinline__ float zc(const Ray& r, int i) const { return cd.z(r, i); }
     __device__ __forceinline__ float zmid(const Ray& r, int k) const {       // handler.py:236
         return __fmul_rn(.5f, __fadd_rn(zc(r, k + 1), zc(r, k)));
     }
@@ -168,7 +193,7 @@ struct FineSampler {
     // importance sample j (u ascending, so the searchsorted position only moves forward)
     __device__ __forceinline__ float sample(const Ray& r, int j) {
         const int ncdf = ns - 1;
-        const float u = u_tab[j];
+        const float u = u_row ? u_row[j] : u_tab[j];
         while (ptr < ncdf && wc[ptr * stride] <= u) ++ptr;                   // searchsorted(right=True), :103
         const int below = max(ptr - 1, 0), above = min(ptr, ncdf - 1);       // :104-105
         const float cb = wc[below * stride], ca = wc[above * stride];

@@ -107,7 +107,11 @@ __global__ void __launch_bounds__(256) render_f32_kernel(RenderArgs a, NetF32 nc
 
     Composite comp; comp.reset();
     FineSampler fs;
-    fs.wc = s_w + tid; fs.stride = kRP; fs.t_tab = s_t; fs.omt_tab = s_omt; fs.u_tab = s_u; fs.ns = ns; fs.ni = ni;
+    fs.wc = s_w + tid; fs.stride = kRP; fs.u_tab = s_u; fs.ns = ns; fs.ni = ni;
+    fs.cd.t_tab = s_t; fs.cd.omt_tab = s_omt; fs.cd.ns = ns;
+    const int64_t rrow = live ? ridx : a.n_rays - 1;
+    fs.cd.jitter = a.t_rand ? a.t_rand + rrow * ns : nullptr;
+    fs.u_row = a.u_rand ? a.u_rand + rrow * ni : nullptr;
     uint32_t flags = 0;
 
     for (int pass = 0; pass < (ni > 0 ? 2 : 1); ++pass) {
@@ -116,7 +120,7 @@ __global__ void __launch_bounds__(256) render_f32_kernel(RenderArgs a, NetF32 nc
         float z_cur = 0.f, z_next = 0.f;
         if (owner) {
             comp.reset();
-            if (pass == 0) { z_cur = coarse_z(ray, s_t[0], s_omt[0]); }
+            if (pass == 0) { z_cur = fs.cd.z(ray, 0); }
             else {
                 fs.prepare(ray);
                 z_cur = a.z_fine_in ? a.z_fine_in[(live ? ridx : a.n_rays - 1) * S] : fs.next(ray);
@@ -125,7 +129,7 @@ __global__ void __launch_bounds__(256) render_f32_kernel(RenderArgs a, NetF32 nc
         for (int s = 0; s < S; ++s) {
             if (owner) {
                 if (s + 1 < S) {
-                    if (pass == 0) z_next = coarse_z(ray, s_t[s + 1], s_omt[s + 1]);
+                    if (pass == 0) z_next = fs.cd.z(ray, s + 1);
                     else z_next = a.z_fine_in ? a.z_fine_in[(live ? ridx : a.n_rays - 1) * S + s + 1] : fs.next(ray);
                 }
                 float px, py, pz; point_at(ray, z_cur, px, py, pz);
@@ -150,7 +154,8 @@ __global__ void __launch_bounds__(256) render_f32_kernel(RenderArgs a, NetF32 nc
             if (owner) {
                 const float rr = s_raw[0 * kRP + tid], rg = s_raw[1 * kRP + tid], rb = s_raw[2 * kRP + tid],
                             rs = s_raw[3 * kRP + tid];
-                const float w = comp.step(rr, rg, rb, rs, z_cur, z_next, s + 1 == S, ray.dnorm);
+                const float* nz = pass == 0 ? a.noise_c : a.noise_f;
+                const float w = comp.step(rr, rg, rb, rs, z_cur, z_next, s + 1 == S, ray.dnorm, nz ? nz[rrow * S + s] : 0.f);
                 if (pass == 0) s_w[s * kRP + tid] = w;
                 if (live) {
                     float* raw = pass == 0 ? a.out.raw_coarse : a.out.raw_fine;

@@ -721,7 +721,10 @@ __global__ void __launch_bounds__(256) render_mfma_kernel(RenderArgs a, NetMfma 
 
     FineSampler fs;
     fs.wc = reinterpret_cast<float*>(smem + SM::WOFF) + wave * (kMfmaMaxSamples * kRaysPerWave) + (lane & 31);
-    fs.stride = kRaysPerWave; fs.t_tab = s_t; fs.omt_tab = s_omt; fs.u_tab = s_u; fs.ns = ns; fs.ni = ni;
+    fs.stride = kRaysPerWave; fs.u_tab = s_u; fs.ns = ns; fs.ni = ni;
+    fs.cd.t_tab = s_t; fs.cd.omt_tab = s_omt; fs.cd.ns = ns;
+    fs.cd.jitter = a.t_rand ? a.t_rand + rclamp * ns : nullptr;       // training-mode forward: host-drawn random rows
+    fs.u_row = a.u_rand ? a.u_rand + rclamp * ni : nullptr;
     __syncthreads();
 
     Composite comp;
@@ -734,6 +737,7 @@ __global__ void __launch_bounds__(256) render_mfma_kernel(RenderArgs a, NetMfma 
         const NetMfma& net = pass == 0 ? nc : nf;
         const float* bias = s_bias + (pass == 0 ? 0 : SM::BIAS_BYTES / 4);
         const int Stot = pass == 0 ? ns : ns + ni;
+        const float* noise = pass == 0 ? a.noise_c : a.noise_f;
         comp.reset();
         if constexpr (SPLIT) {
             // depths are produced strictly in order: zq[0..3] = this iteration's four samples, zq[4] = the first of the next
@@ -741,7 +745,7 @@ __global__ void __launch_bounds__(256) render_mfma_kernel(RenderArgs a, NetMfma 
             auto gen = [&]() -> float {
                 const int i = produced++;
                 if (i >= Stot) return 0.f;
-                if (pass == 0) return coarse_z(ray, s_t[i], s_omt[i]);
+                if (pass == 0) return fs.cd.z(ray, i);
                 return a.z_fine_in ? a.z_fine_in[rclamp * Stot + i] : fs.next(ray);
             };
             if (pass == 1) fs.prepare(ray);
@@ -810,7 +814,7 @@ __global__ void __launch_bounds__(256) render_mfma_kernel(RenderArgs a, NetMfma 
 #endif
                 if (own_valid) {
                     xch[(it & 1) * (kWaves * kRaysPerWave) + wave * kRaysPerWave + (lane & 31)] =
-                        Composite::shade(rr, rg, rb, rs, z_own, z_nxt, s_own + 1 == Stot, ray.dnorm);
+                        Composite::shade(rr, rg, rb, rs, z_own, z_nxt, s_own + 1 == Stot, ray.dnorm, noise ? noise[rclamp * Stot + s_own] : 0.f);
                     if (lane_live) {
                         float* raw = pass == 0 ? a.out.raw_coarse : a.out.raw_fine;
                         if (raw) {
@@ -833,7 +837,7 @@ __global__ void __launch_bounds__(256) render_mfma_kernel(RenderArgs a, NetMfma 
             __syncthreads();   // the exchange buffers are free again for the next pass
         } else {
             float z_cur, z_next = 0.f;
-            if (pass == 0) z_cur = coarse_z(ray, s_t[0], s_omt[0]);
+            if (pass == 0) z_cur = fs.cd.z(ray, 0);
             else {
                 fs.prepare(ray);
                 z_cur = a.z_fine_in ? a.z_fine_in[rclamp * Stot] : fs.next(ray);
@@ -851,7 +855,7 @@ __global__ void __launch_bounds__(256) render_mfma_kernel(RenderArgs a, NetMfma 
     #pragma unroll
                 for (int i = 0; i < S::N_L0; ++i) wk.piece(i);
                 if (s + 1 < Stot) {
-                    if (pass == 0) z_next = coarse_z(ray, s_t[s + 1], s_omt[s + 1]);
+                    if (pass == 0) z_next = fs.cd.z(ray, s + 1);
                     else z_next = a.z_fine_in ? a.z_fine_in[rclamp * Stot + s + 1] : fs.next(ray);
                 }
                 float px, py, pz;
@@ -878,7 +882,7 @@ __global__ void __launch_bounds__(256) render_mfma_kernel(RenderArgs a, NetMfma 
     #ifdef NWE_STAMPS
                 const unsigned long long t3 = __builtin_amdgcn_s_memtime();
     #endif
-                const float w = comp.step(rr, rg, rb, rs, z_cur, z_next, s + 1 == Stot, ray.dnorm);
+                const float w = comp.step(rr, rg, rb, rs, z_cur, z_next, s + 1 == Stot, ray.dnorm, noise ? noise[rclamp * Stot + s] : 0.f);
                 if (pass == 0) fs.wc[s * kRaysPerWave] = w;
                 if (lane_live) {
                     float* raw = pass == 0 ? a.out.raw_coarse : a.out.raw_fine;

@@ -180,15 +180,18 @@ class NeRFReplicaInferenceHandler:
         return out
 
     def _render_rays(self, flat_rays: torch.Tensor, outputs: Optional[Sequence[str]] = None,
-                     precision: Optional[str] = None) -> Dict[str, torch.Tensor]:
-        """handler.py:187-201: [R,11] rays -> dict keyed like the reference's output dict."""
+                     precision: Optional[str] = None,
+                     train: Optional[Dict[str, Optional[torch.Tensor]]] = None) -> Dict[str, torch.Tensor]:
+        """handler.py:187-201: [R,11] rays -> dict keyed like the reference's output dict.  ``train`` = the forward pass of
+        the training handler's renderer (nerf_replica_training_handler.py:536-600) on caller-drawn random numbers, see
+        Renderer.render_rays."""
         r = self._need_renderer()
         fine = self._n_importance > 0
         if outputs is None:
             outputs = ["rgb", "disp", "acc", "depth", "rgb_coarse", "disp_coarse", "acc_coarse", "depth_coarse"]
             if fine:
                 outputs.append("z_std")
-        res = r.render_rays(flat_rays, precision=precision or self._precision, outputs=outputs)
+        res = r.render_rays(flat_rays, precision=precision or self._precision, outputs=outputs, train=train)
         rename = {"rgb": "rgb_fine", "disp": "disp_fine", "acc": "acc_fine", "depth": "depth_fine"}
         return {rename.get(k, k): v for k, v in res.items() if not k.startswith("_")}
 

@@ -164,9 +164,16 @@ class Renderer:
 
     def render_rays(self, rays: torch.Tensor, *, precision: str = "f16x3",
                     outputs: Sequence[str] = ("rgb", "depth", "acc"),
-                    debug_fine_depths: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
+                    debug_fine_depths: Optional[torch.Tensor] = None,
+                    train: Optional[Dict[str, Optional[torch.Tensor]]] = None) -> Dict[str, torch.Tensor]:
         """rays: [R,11] fp32 on this renderer's device, the layout of nerf/rays/rays.py:26-30.
-        ``debug_fine_depths`` ([R, Ns+Ni], test hook) replaces the importance sampling of the fine pass."""
+        ``debug_fine_depths`` ([R, Ns+Ni], test hook) replaces the importance sampling of the fine pass.
+
+        ``train`` switches on the training-mode forward of nerf/training/nerf_replica_training_handler.py:553-580 with
+        random numbers drawn by the caller where the reference draws them (any key may be missing / None):
+        ``t_rand`` [R,Ns] = torch.rand (stratified jitter), ``noise_coarse`` [R,Ns] and ``noise_fine`` [R,Ns+Ni] =
+        torch.randn * raw_noise_std (model_utils.py:64-71), ``u`` [R,Ni] = torch.rand of sample_pdf(det=False)
+        (rays.py:98; sorted per ray here, which changes no output because the depths are sorted afterwards)."""
         if rays.dim() != 2 or rays.shape[1] != 11 or rays.dtype != torch.float32:
             raise ValueError("rays must be float32 [R,11]")
         rays = rays.to(self.device).contiguous()
@@ -175,12 +182,36 @@ class Renderer:
             if tuple(debug_fine_depths.shape) != (rays.shape[0], self.n_samples + self.n_importance):
                 raise ValueError("debug_fine_depths must be [R, n_samples + n_importance]")
             self._lib.nwe_debug_set_fine_depths(self._ctx, debug_fine_depths.data_ptr())
+        keep = []
+        if train:
+            R, ns, ni = rays.shape[0], self.n_samples, self.n_importance
+            shapes = {"t_rand": (R, ns), "noise_coarse": (R, ns), "noise_fine": (R, ns + ni), "u": (R, ni)}
+            ptrs = []
+            for key in ("t_rand", "noise_coarse", "noise_fine", "u"):
+                t = train.get(key)
+                if t is None:
+                    ptrs.append(None)
+                    continue
+                t = t.to(self.device, torch.float32)
+                if tuple(t.shape) != shapes[key]:
+                    raise ValueError(f"train[{key!r}] must be {shapes[key]}")
+                if key == "u":
+                    t = torch.sort(t, dim=-1).values
+                t = t.contiguous()
+                keep.append(t)
+                ptrs.append(t.data_ptr())
+            unknown = set(train) - set(shapes)
+            if unknown:
+                raise ValueError(f"unknown train keys {sorted(unknown)}")
+            self._lib.nwe_set_train_tables(self._ctx, *ptrs)
         with torch.cuda.device(self.device):
             o, res = self._alloc(rays.shape[0], outputs)
             stream = torch.cuda.current_stream(self.device).cuda_stream
             rc = self._lib.nwe_render_rays(self._ctx, rays.data_ptr(), rays.shape[0], _lib.PRECISIONS[precision], C.byref(o), stream)
         self._check(rc, "nwe_render_rays")
         res["_keepalive_rays"] = rays
+        if keep:
+            res["_keepalive_train"] = keep
         if debug_fine_depths is not None:
             res["_keepalive_depths"] = debug_fine_depths
         return res

@@ -269,6 +269,50 @@ def main() -> None:
     for k in ("rgb_fine", "depth_fine", "acc_fine", "disp_fine", "z_std", "rgb_coarse", "depth_coarse", "acc_coarse"):
         fog[k] = ref[k].numpy()
     np.savez_compressed(os.path.join(GOLD, "e2e_fog.npz"), **fog)
+
+    # (9) training-mode forward -----------------------------------------------------
+    # The reference draws its random numbers inside raw2outputs / sample_pdf from torch's global generator; seeding it
+    # and repeating the same draw outside gives the tensors the oracle (and the kernel) take as inputs.
+    print("[9] training-mode building blocks")
+    g9 = torch.Generator().manual_seed(909)
+    S = 16
+    z9 = (0.1 * (1 - torch.linspace(0, 1, S)) + 10.0 * torch.linspace(0, 1, S)).expand(8, S).contiguous()
+    raw9 = torch.randn(8, S, 4, generator=g9) * 2
+    d9 = torch.randn(8, 3, generator=g9)
+    torch.manual_seed(4242)
+    ref = ref_raw2outputs(raw9, z9, d9, 0.7, False, endpoint_feat=False, cuda_enabled=False)
+    torch.manual_seed(4242)
+    noise9 = torch.randn(raw9[..., 3].shape) * 0.7                                    # model_utils.py:65
+    mine = O.raw2outputs(raw9, z9, d9, noise=noise9)
+    for nm, a, b in zip(("rgb", "disp", "acc", "weights", "depth"), mine, ref[:5]):
+        same(a, b, f"raw2outputs with sigma noise: {nm}")
+    train = {"r2o_raw": raw9.numpy(), "r2o_z": z9.numpy(), "r2o_d": d9.numpy(), "r2o_noise": noise9.numpy(),
+             "r2o_rgb": ref[0].numpy(), "r2o_acc": ref[2].numpy(), "r2o_weights": ref[3].numpy(), "r2o_depth": ref[4].numpy()}
+    torch.manual_seed(4243)
+    ref = ref_sample_pdf(zmid, w, Ni, det=False)
+    torch.manual_seed(4243)
+    u9 = torch.rand(list(w.shape[:-1]) + [Ni])                                          # rays.py:98
+    same(O.sample_pdf(zmid, w, Ni, u=u9), ref, "sample_pdf det=False")
+    # the kernel takes u sorted per ray: element-wise function + the sort of handler.py:243 => same sorted depths
+    same(torch.sort(O.sample_pdf(zmid, w, Ni, u=torch.sort(u9, -1).values), -1).values, torch.sort(ref, -1).values,
+         "sample_pdf on sorted u == sorted sample_pdf")
+    train.update({"pdf_bins": zmid.numpy(), "pdf_weights": w.numpy(), "pdf_u": u9.numpy(), "pdf_samples": ref.numpy()})
+    # end to end on 512 rays of the fog scene; the jitter step (training_handler.py:553-562) exists only as the oracle's
+    # restatement (that handler cannot be imported: hard-coded .cuda(), tensorboard) -- recorded as such
+    idx9 = (torch.arange(512) * 1223 + 11) % (800 * 800)
+    rays9 = full[idx9].contiguous()
+    tr = {"t_rand": torch.rand(512, 64, generator=g9), "noise_coarse": torch.randn(512, 64, generator=g9) * 0.02,   # small next to the fog density (0.08): every bin keeps weight
+          "noise_fine": torch.randn(512, 192, generator=g9) * 0.5, "u": torch.rand(512, 128, generator=g9)}
+    res = O.render_rays(rays9, {k: torch.from_numpy(v) for k, v in sd_fog.items()}, tf, O.RenderConfig(), train=tr)
+    train.update({"e2e_idx": idx9.numpy(), "e2e_pose": POSES["hor30"][0].numpy(),
+                  "e2e_source": np.array("oracle restatement; building blocks pinned above")})
+    for k, v in tr.items():
+        train["e2e_in_" + k] = v.numpy()
+    for k in ("rgb_fine", "depth_fine", "acc_fine", "z_std", "rgb_coarse", "depth_coarse", "acc_coarse", "z_coarse"):
+        train["e2e_" + k] = res[k].numpy()
+    train["e2e_z_fine_first64"] = res["z_fine"][:64].numpy()
+    train["e2e_sigma_last_fine"] = (res["raw_fine"][:, -1, 3] + tr["noise_fine"][:, -1]).numpy()
+    np.savez_compressed(os.path.join(GOLD, "train_mode.npz"), **train)
     print("goldens written to", GOLD)
 
 

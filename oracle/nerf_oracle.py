@@ -62,8 +62,9 @@ def create_rays(c2w: torch.Tensor, H: int, W: int, fx: float, fy: float, cx: flo
     return torch.cat(cols, -1)
 
 
-def sample_pdf(bins: torch.Tensor, weights: torch.Tensor, n_samples: int) -> torch.Tensor:
-    """Deterministic inverse-CDF sampling, nerf/rays/rays.py:74-121 with det=True.
+def sample_pdf(bins: torch.Tensor, weights: torch.Tensor, n_samples: int, u: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Inverse-CDF sampling, nerf/rays/rays.py:74-121: det=True (u = linspace, :95) or, with `u` [N, n_samples], the
+    det=False branch on the caller's uniform numbers (the reference draws them with torch.rand, :98).
 
     bins [N, Ns-1] (interval mid points), weights [N, Ns-2] -> samples [N, n_samples].
     """
@@ -71,8 +72,10 @@ def sample_pdf(bins: torch.Tensor, weights: torch.Tensor, n_samples: int) -> tor
     pdf = weights / torch.sum(weights, -1, keepdim=True)            # rays.py:88
     cdf = torch.cumsum(pdf, -1)                                     # rays.py:89
     cdf = torch.cat([torch.zeros_like(cdf[..., :1]), cdf], -1)      # rays.py:90
-    u = torch.linspace(0., 1., steps=n_samples)                     # rays.py:95
-    u = u.expand(list(cdf.shape[:-1]) + [n_samples]).contiguous()
+    if u is None:
+        u = torch.linspace(0., 1., steps=n_samples)                 # rays.py:95
+        u = u.expand(list(cdf.shape[:-1]) + [n_samples])
+    u = u.contiguous()                                              # rays.py:101
     inds = torch.searchsorted(cdf, u, right=True)                   # rays.py:103
     below = torch.clamp(inds - 1, min=0)                            # rays.py:104
     above = torch.clamp(inds, max=cdf.shape[-1] - 1)                # rays.py:105
@@ -177,16 +180,18 @@ def run_network(pts: torch.Tensor, viewdirs: torch.Tensor, state: Dict[str, torc
 # --------------------------------------------------------------------------
 
 
-def raw2outputs(raw: torch.Tensor, z_vals: torch.Tensor, rays_d: torch.Tensor, white_bkgd: bool = False):
+def raw2outputs(raw: torch.Tensor, z_vals: torch.Tensor, rays_d: torch.Tensor, white_bkgd: bool = False,
+                noise: Optional[torch.Tensor] = None):
     """raw [N,S,4], z [N,S], d [N,3] -> rgb [N,3], disp [N], acc [N], weights [N,S], depth [N].
 
-    model_utils.py:49-100 on the cuda_enabled=False branch, raw_noise_std = 0.
+    model_utils.py:49-100 on the cuda_enabled=False branch; `noise` [N,S] is the reference's
+    `torch.randn(raw[..., 3].shape) * raw_noise_std` (:64-66), None = raw_noise_std 0 (:69, noise = 0.).
     """
     dists = z_vals[..., 1:] - z_vals[..., :-1]                                       # :51
     dists = torch.cat([dists, torch.Tensor([1e10]).expand(dists[..., :1].shape)], -1)  # :56
     dists = dists * torch.norm(rays_d[..., None, :], dim=-1)                         # :60
     rgb = torch.sigmoid(raw[..., :3])                                                # :62
-    alpha = 1. - torch.exp(-F.relu(raw[..., 3] + 0.) * dists)                        # :49,:71
+    alpha = 1. - torch.exp(-F.relu(raw[..., 3] + (0. if noise is None else noise)) * dists)   # :49,:71
     trans = torch.cumprod(torch.cat([torch.ones((alpha.shape[0], 1)), 1. - alpha + 1e-10], -1), -1)[:, :-1]  # :79-80
     weights = alpha * trans
     rgb_map = torch.sum(weights[..., None] * rgb, -2)                                # :84
@@ -214,30 +219,43 @@ class RenderConfig:
 
 
 def volumetric_rendering(ray_batch: torch.Tensor, coarse: Dict[str, torch.Tensor],
-                         fine: Optional[Dict[str, torch.Tensor]], cfg: RenderConfig) -> Dict[str, torch.Tensor]:
+                         fine: Optional[Dict[str, torch.Tensor]], cfg: RenderConfig,
+                         train: Optional[Dict[str, Optional[torch.Tensor]]] = None) -> Dict[str, torch.Tensor]:
     """One ray chunk [N,11] -> the output dict of handler.py:203-277.
 
     With n_importance == 0 the reference raises UnboundLocalError (handler.py:263); here the coarse
     outputs are returned alone so BASELINE configs C1/C2 have an oracle.
+
+    `train` = the training-mode forward of nerf/training/nerf_replica_training_handler.py:536-600 (same function, three
+    extra steps) on caller-drawn random numbers: "t_rand" [N,Ns] (:560), "noise_coarse" [N,Ns] / "noise_fine" [N,Ns+Ni]
+    (randn * raw_noise_std, model_utils.py:64-66), "u" [N,Ni] (rays.py:98).  That handler cannot be imported here
+    (hard-coded .cuda(), tensorboard); the jitter lines are restated from the file, raw2outputs' noise branch and
+    sample_pdf's det=False branch are pinned against the reference by tests/golden/train_mode.npz.
     """
+    train = train or {}
     rays_o, rays_d, viewdirs = ray_batch[:, 0:3], ray_batch[:, 3:6], ray_batch[:, -3:]   # :210-211
     bounds = ray_batch[..., 6:8].reshape(-1, 1, 2)
     near, far = bounds[..., 0], bounds[..., 1]                                            # :213-214
     t_vals = torch.linspace(0., 1., steps=cfg.n_samples)                                  # :216
     z_vals = near * (1. - t_vals) + far * t_vals                                          # :218
     z_vals = z_vals.expand([ray_batch.shape[0], cfg.n_samples])
+    if train.get("t_rand") is not None:                                                   # training_handler.py:553-562
+        mids = .5 * (z_vals[..., 1:] + z_vals[..., :-1])
+        upper = torch.cat([mids, z_vals[..., -1:]], -1)
+        lower = torch.cat([z_vals[..., :1], mids], -1)
+        z_vals = lower + (upper - lower) * train["t_rand"]
     pts = rays_o[..., None, :] + rays_d[..., None, :] * z_vals[..., :, None]              # :223
     raw_c = run_network(pts, viewdirs, coarse, cfg.freqs_xyz, cfg.freqs_dir, cfg.net_chunk)
-    rgb_c, disp_c, acc_c, w_c, depth_c = raw2outputs(raw_c, z_vals, rays_d, cfg.white_bkgd)
+    rgb_c, disp_c, acc_c, w_c, depth_c = raw2outputs(raw_c, z_vals, rays_d, cfg.white_bkgd, train.get("noise_coarse"))
     out = {"rgb_coarse": rgb_c, "disp_coarse": disp_c, "acc_coarse": acc_c, "depth_coarse": depth_c,
            "raw_coarse": raw_c, "weights_coarse": w_c, "z_coarse": z_vals}
     if cfg.n_importance > 0:
         z_mid = .5 * (z_vals[..., 1:] + z_vals[..., :-1])                                 # :236
-        z_samples = sample_pdf(z_mid, w_c[..., 1:-1], cfg.n_importance)                   # :237 (always det)
+        z_samples = sample_pdf(z_mid, w_c[..., 1:-1], cfg.n_importance, train.get("u"))   # :237 (always det in inference)
         z_all, _ = torch.sort(torch.cat([z_vals, z_samples], -1), -1)                     # :243
         pts_f = rays_o[..., None, :] + rays_d[..., None, :] * z_all[..., :, None]         # :246
         raw_f = run_network(pts_f, viewdirs, fine, cfg.freqs_xyz, cfg.freqs_dir, cfg.net_chunk)
-        rgb_f, disp_f, acc_f, w_f, depth_f = raw2outputs(raw_f, z_all, rays_d, cfg.white_bkgd)
+        rgb_f, disp_f, acc_f, w_f, depth_f = raw2outputs(raw_f, z_all, rays_d, cfg.white_bkgd, train.get("noise_fine"))
         out.update({"rgb_fine": rgb_f, "disp_fine": disp_f, "acc_fine": acc_f, "depth_fine": depth_f,
                     "z_std": torch.std(z_samples, dim=-1, unbiased=False),                # :267
                     "raw_fine": raw_f, "z_fine": z_all, "z_samples": z_samples})
@@ -258,13 +276,15 @@ def fine_pass_given_depths(ray_batch: torch.Tensor, z_all: torch.Tensor, fine: D
 
 
 def render_rays(flat_rays: torch.Tensor, coarse, fine, cfg: RenderConfig,
-                keep: Optional[Sequence[str]] = None) -> Dict[str, torch.Tensor]:
+                keep: Optional[Sequence[str]] = None,
+                train: Optional[Dict[str, Optional[torch.Tensor]]] = None) -> Dict[str, torch.Tensor]:
     """All rays of a frame in `cfg.chunk`-ray chunks, concatenated per key.
     utils/batch_utils.py:7-25 + handler.py:187-201.  `keep` limits the keys retained (memory)."""
     parts: Dict[str, list] = {}
     with torch.no_grad():
         for i in range(0, flat_rays.shape[0], cfg.chunk):
-            res = volumetric_rendering(flat_rays[i:i + cfg.chunk], coarse, fine, cfg)
+            tr = None if train is None else {k: (None if v is None else v[i:i + cfg.chunk]) for k, v in train.items()}
+            res = volumetric_rendering(flat_rays[i:i + cfg.chunk], coarse, fine, cfg, tr)
             for k, v in res.items():
                 if keep is None or k in keep:
                     parts.setdefault(k, []).append(v)

@@ -471,3 +471,50 @@ def test_work_decompositions_are_bit_identical(monkeypatch):
                 a, b = res["0", prec][k], res["1", prec][k]
                 assert torch.equal(torch.nan_to_num(a, nan=-7.0), torch.nan_to_num(b, nan=-7.0)), (D, Wn, ns, ni, prec, k)
     monkeypatch.delenv("NWE_SPLIT")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+def test_training_mode_forward(golden_dir, precision, monkeypatch):
+    """SURVEY 8 f4, forward only: stratified jitter (training_handler.py:553-562), sigma noise (model_utils.py:64-71)
+    and sample_pdf(det=False) (rays.py:98) on host-drawn random numbers (nwe_set_train_tables), against the oracle's
+    training-mode golden (its noise / random-u building blocks are pinned against the reference, the jitter lines are a
+    restatement: oracle/make_goldens.py section 9).  Thin-fog coarse net, every ray, both work decompositions."""
+    g = np.load(os.path.join(golden_dir, "train_mode.npz"))
+    r = nwe_amd.Renderer(0)
+    r.set_network(0, nwe_amd.synthetic.thin_fog(_sd(1000, 8, 256)))
+    r.set_network(1, _sd(1001, 8, 256))
+    r.set_sampling(64, 128)
+    fx, fy, cx, cy = O.intrinsics(800, 800)
+    full = O.create_rays(torch.from_numpy(g["e2e_pose"])[None], 800, 800, fx, fy, cx, cy, 0.1, 10.0)[0]
+    rays = full[torch.from_numpy(g["e2e_idx"])].contiguous().cuda()
+    tr = {k: torch.from_numpy(g["e2e_in_" + k]) for k in ("t_rand", "noise_coarse", "noise_fine", "u")}
+    outs = ("rgb", "depth", "acc", "z_std", "rgb_coarse", "depth_coarse", "acc_coarse", "z_fine", "sample_cond")
+    res = {}
+    for mode in (("0", "1") if precision != "f32" else ("0",)):
+        monkeypatch.setenv("NWE_SPLIT", mode)
+        res[mode] = r.render_rays(rays, precision=precision, outputs=outs, train=tr)
+    monkeypatch.delenv("NWE_SPLIT")
+    out = res["0"]
+    if "1" in res:
+        for k in outs:
+            assert torch.equal(res["0"][k], res["1"][k]), k
+    cliff = np.abs(g["e2e_sigma_last_fine"]) < 1e-5
+    err = np.abs(out["rgb"].cpu().numpy() - g["e2e_rgb_fine"])
+    zerr = np.abs(out["z_fine"][:64].cpu().numpy() - g["e2e_z_fine_first64"])
+    print(f"[{precision} train] rgb max err", err[~cliff].max(), "coarse", np.abs(out["rgb_coarse"].cpu().numpy() - g["e2e_rgb_coarse"]).max(),
+          "z_fine", zerr.max(), "z_std", np.abs(out["z_std"].cpu().numpy() - g["e2e_z_std"]).max(), "cliff", int(cliff.sum()),
+          "min cdf step", float(out["sample_cond"].min()))
+    assert np.abs(out["rgb_coarse"].cpu().numpy() - g["e2e_rgb_coarse"]).max() <= RGB_TOL
+    assert np.abs(out["depth_coarse"].cpu().numpy() - g["e2e_depth_coarse"]).max() / FAR <= 1e-4
+    assert zerr.max() <= 1e-4      # 1e-5 of far; random u and uneven strata are conditioned a little worse than inference (2e-5)
+    assert err[~cliff].max() <= RGB_TOL
+    assert np.abs(out["depth"].cpu().numpy() - g["e2e_depth_fine"])[~cliff].max() / FAR <= 1e-4
+    assert np.abs(out["acc"].cpu().numpy() - g["e2e_acc_fine"])[~cliff].max() <= 1e-4
+    assert np.abs(out["z_std"].cpu().numpy() - g["e2e_z_std"]).max() <= 1e-4
+    # the tables are one-shot: the next call is plain inference again, and differs
+    plain = r.render_rays(rays, precision=precision, outputs=("rgb",))
+    assert (plain["rgb"] - out["rgb"]).abs().max().item() > 1e-3
+    with pytest.raises(ValueError):
+        r.render_rays(rays, precision=precision, train={"t_rand": torch.zeros(3, 64)})
+    r.close()

@@ -120,3 +120,45 @@ def test_end_to_end_c3_subset_small(golden_dir):
     _close(out["z_fine"].numpy(), g["z_fine_first64_hor0"], 1e-6)
     cliff = np.abs(g["sigma_last_fine_hor0"][:64]) < 1e-5
     _close(out["rgb_fine"].numpy()[~cliff], g["rgb_fine_hor0"][:64][~cliff], 5e-5)
+
+
+def test_training_mode_building_blocks(golden_dir):
+    """raw2outputs with sigma noise (model_utils.py:64-71) and sample_pdf(det=False) (rays.py:98) on the random
+    numbers the REFERENCE drew (captured by seeding torch's global generator, oracle/make_goldens.py section 9)."""
+    g = _load(golden_dir, "train_mode.npz")
+    rgb, disp, acc, w, depth = O.raw2outputs(torch.from_numpy(g["r2o_raw"]), torch.from_numpy(g["r2o_z"]),
+                                             torch.from_numpy(g["r2o_d"]), noise=torch.from_numpy(g["r2o_noise"]))
+    _close(rgb.numpy(), g["r2o_rgb"]); _close(acc.numpy(), g["r2o_acc"])
+    _close(w.numpy(), g["r2o_weights"]); _close(depth.numpy(), g["r2o_depth"])
+    # the noise matters: without it the result is different
+    assert np.abs(O.raw2outputs(torch.from_numpy(g["r2o_raw"]), torch.from_numpy(g["r2o_z"]), torch.from_numpy(g["r2o_d"]))[3].numpy()
+                  - g["r2o_weights"]).max() > 1e-3
+    s = O.sample_pdf(torch.from_numpy(g["pdf_bins"]), torch.from_numpy(g["pdf_weights"]), g["pdf_u"].shape[-1],
+                     u=torch.from_numpy(g["pdf_u"]))
+    _close(s.numpy(), g["pdf_samples"])
+    # what the kernel does: u sorted per ray, then the union is sorted anyway (handler.py:243)
+    s_sorted = O.sample_pdf(torch.from_numpy(g["pdf_bins"]), torch.from_numpy(g["pdf_weights"]), g["pdf_u"].shape[-1],
+                            u=torch.sort(torch.from_numpy(g["pdf_u"]), -1).values)
+    _close(np.sort(s_sorted.numpy(), -1), np.sort(g["pdf_samples"], -1))
+
+
+def test_training_mode_end_to_end_small(golden_dir):
+    """64 rays of the training-mode golden through the oracle (the 512-ray set is checked on the GPU against the HIP path)."""
+    g = _load(golden_dir, "train_mode.npz")
+    sc = {k: torch.from_numpy(v) for k, v in nwe_amd.synthetic.thin_fog(nwe_amd.synthetic.make_state_dict(1000, 8, 256)).items()}
+    sf = {k: torch.from_numpy(v) for k, v in nwe_amd.synthetic.make_state_dict(1001, 8, 256).items()}
+    fx, fy, cx, cy = O.intrinsics(800, 800)
+    full = O.create_rays(torch.from_numpy(g["e2e_pose"])[None], 800, 800, fx, fy, cx, cy, 0.1, 10.0)[0]
+    rays = full[torch.from_numpy(g["e2e_idx"][:64])].contiguous()
+    tr = {k: torch.from_numpy(g["e2e_in_" + k][:64]) for k in ("t_rand", "noise_coarse", "noise_fine", "u")}
+    out = O.render_rays(rays, sc, sf, O.RenderConfig(), train=tr)
+    _close(out["z_coarse"].numpy(), g["e2e_z_coarse"][:64], 1e-6)
+    _close(out["z_fine"].numpy(), g["e2e_z_fine_first64"], 1e-5)
+    _close(out["rgb_fine"].numpy(), g["e2e_rgb_fine"][:64], 5e-5)
+    # jitter keeps every depth inside its stratum (training_handler.py:553-562)
+    t = torch.linspace(0., 1., 64)
+    base = (0.1 * (1. - t) + 10.0 * t).numpy()
+    mids = .5 * (base[1:] + base[:-1])
+    lo, hi = np.concatenate([base[:1], mids]), np.concatenate([mids, base[-1:]])
+    zc = g["e2e_z_coarse"]
+    assert (zc >= lo - 1e-6).all() and (zc <= hi + 1e-6).all() and np.abs(zc - base).max() > 1e-2
