@@ -145,6 +145,10 @@ float nwe_packed_scale(const nwe_ctx *ctx, int which);
  * reference's own depths and compare the fine pass alone. */
 int nwe_debug_set_fine_depths(nwe_ctx *ctx, const float *z_dev);
 
+/* rendering.white_background of the reference's YAML (nerf/models/model_utils.py:97-98): when on, every rgb output
+ * (coarse and fine) is rgb + (1 - acc).  Off by default, as in all four office configs. */
+int nwe_set_white_background(nwe_ctx *ctx, int on);
+
 /* Training-mode forward (nerf/training/nerf_replica_training_handler.py:553-580; forward only): the NEXT
  * nwe_render_rays call uses random numbers drawn by the caller exactly where the reference calls torch.rand /
  * torch.randn, one row per ray of that call (DEVICE pointers, each may be NULL = the inference behaviour); cleared

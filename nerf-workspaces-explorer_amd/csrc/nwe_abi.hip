@@ -43,6 +43,7 @@ struct nwe_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
     const float* dbg_z_fine = nullptr;
+    int white_bkgd = 0;
     const float *trn_t = nullptr, *trn_nc = nullptr, *trn_nf = nullptr, *trn_u = nullptr;   // nwe_set_train_tables, one call
     std::string err;
 };
@@ -233,6 +234,7 @@ int check_ready(nwe_ctx* ctx, const nwe_outputs* out, int precision) {
 }
 
 int launch(nwe_ctx* ctx, RenderArgs& a, int precision, void* stream_) {
+    a.white_bkgd = ctx->white_bkgd;
     hipStream_t stream = (hipStream_t)stream_;
     a.t_vals = ctx->d_t; a.omt_vals = ctx->d_omt; a.u_vals = ctx->d_u;
     a.n_samples = ctx->ns; a.n_importance = ctx->ni;
@@ -462,6 +464,12 @@ float nwe_packed_scale(const nwe_ctx* c, int which) {
 int nwe_debug_set_fine_depths(nwe_ctx* c, const float* z_dev) {
     if (!c) return NWE_ERR_INVALID;
     c->dbg_z_fine = z_dev;
+    return NWE_OK;
+}
+
+int nwe_set_white_background(nwe_ctx* c, int on) {
+    if (!c) return NWE_ERR_INVALID;
+    c->white_bkgd = on ? 1 : 0;
     return NWE_OK;
 }
 

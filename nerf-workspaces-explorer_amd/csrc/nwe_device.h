@@ -37,6 +37,7 @@ struct RenderArgs {
     const float* noise_c;    // [n_rays, ns]      sigma noise, already times raw_noise_std   (model_utils.py:64-71)
     const float* noise_f;    // [n_rays, ns+ni]
     const float* u_rand;     // [n_rays, ni]      inverse-CDF arguments, ASCENDING per ray   (rays.py:98)
+    int white_bkgd;          // rendering.white_background (model_utils.py:97-98): rgb += 1 - acc
     int n_samples, n_importance;
     unsigned long long* stamps;  // diagnostic builds (-DNWE_STAMPS): per-wave cycle sums, else unused
     nwe_outputs out;
@@ -269,8 +270,12 @@ __device__ __forceinline__ bool bad(float x) { return !(fabsf(x) <= 3.402823466e
 
 // Writes the per-ray results of one pass into the fine (handler.py:263-266) or coarse (:257-260) slots
 // and returns the NaN/Inf flag bits of what it wrote (handler.py:273-275).
-__device__ __forceinline__ uint32_t store_ray(const nwe_outputs& o, int64_t idx, const Composite& c, bool fine) {
+__device__ __forceinline__ uint32_t store_ray(const nwe_outputs& o, int64_t idx, Composite c, bool fine, bool white_bkgd = false) {
     const float d = c.disp();
+    if (white_bkgd) {                                                        // model_utils.py:97-98: rgb + (1 - acc)
+        const float rest = __fsub_rn(1.f, c.acc);
+        c.r = __fadd_rn(c.r, rest); c.g = __fadd_rn(c.g, rest); c.b = __fadd_rn(c.b, rest);
+    }
     float* rgb = fine ? o.rgb : o.rgb_coarse;
     float* depth = fine ? o.depth : o.depth_coarse;
     float* acc = fine ? o.acc : o.acc_coarse;

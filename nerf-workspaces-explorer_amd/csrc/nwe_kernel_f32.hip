@@ -172,8 +172,8 @@ __global__ void __launch_bounds__(256) render_f32_kernel(RenderArgs a, NetF32 nc
             // ordered before their own writes at the top of the next iteration.
         }
         if (live) {
-            flags |= store_ray(a.out, ridx, comp, pass == 1);
-            if (ni == 0) flags |= store_ray(a.out, ridx, comp, true);   // coarse-only: fill the "fine" slots too
+            flags |= store_ray(a.out, ridx, comp, pass == 1, a.white_bkgd != 0);
+            if (ni == 0) flags |= store_ray(a.out, ridx, comp, true, a.white_bkgd != 0);   // coarse-only: fill the "fine" slots too
             if (pass == 1 && a.out.z_std) {
                 const float zs = fs.z_std();
                 a.out.z_std[ridx] = zs;

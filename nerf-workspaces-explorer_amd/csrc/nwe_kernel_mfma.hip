@@ -900,8 +900,8 @@ __global__ void __launch_bounds__(256) render_mfma_kernel(RenderArgs a, NetMfma 
             }
         }
         if (live) {
-            flags |= store_ray(a.out, ridx, comp, pass == 1);
-            if (ni == 0) flags |= store_ray(a.out, ridx, comp, true);
+            flags |= store_ray(a.out, ridx, comp, pass == 1, a.white_bkgd != 0);
+            if (ni == 0) flags |= store_ray(a.out, ridx, comp, true, a.white_bkgd != 0);
             if (pass == 1 && a.out.z_std) {
                 const float zs = fs.z_std();
                 a.out.z_std[ridx] = zs;

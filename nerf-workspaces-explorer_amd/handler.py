@@ -74,8 +74,6 @@ class NeRFReplicaInferenceHandler:
         self._depth_close_bound, self._depth_far_bound = cfg.get_param(("rendering", "depth_range"), list)
         if not self._use_view_dirs:
             raise NotImplementedError("only use_view_dirs=True networks are supported (all reference configs)")
-        if self._white_bkgd:
-            raise NotImplementedError("white_background=True is not supported (False in every reference config)")
         if self._endpoint_feat:
             raise NotImplementedError("endpoint_feat=True is not supported (False in every reference config)")
         self._fx, self._fy, self._cx, self._cy = pinhole_intrinsics(self._img_h, self._img_w)
@@ -105,6 +103,7 @@ class NeRFReplicaInferenceHandler:
         if fine is not None:
             self._renderer.set_network(_lib.NET_FINE, fine)
         self._renderer.set_sampling(self._n_samples, self._n_importance)
+        self._renderer.set_white_background(self._white_bkgd)                     # handler.py:57,231,253
 
     def _need_renderer(self) -> Renderer:
         if self._renderer is None:

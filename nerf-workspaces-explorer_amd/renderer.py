@@ -216,6 +216,10 @@ class Renderer:
             res["_keepalive_depths"] = debug_fine_depths
         return res
 
+    def set_white_background(self, on: bool) -> None:
+        """rendering.white_background (model_utils.py:97-98): rgb += 1 - acc on every rgb output."""
+        self._check(self._lib.nwe_set_white_background(self._ctx, 1 if on else 0), "nwe_set_white_background")
+
     def to8b(self, rgb: torch.Tensor) -> torch.Tensor:
         rgb = rgb.contiguous()
         out = torch.empty(rgb.shape, dtype=torch.uint8, device=rgb.device)

@@ -518,3 +518,21 @@ def test_training_mode_forward(golden_dir, precision, monkeypatch):
     with pytest.raises(ValueError):
         r.render_rays(rays, precision=precision, train={"t_rand": torch.zeros(3, 64)})
     r.close()
+
+
+@pytest.mark.gpu
+def test_white_background(r_c1):
+    """rendering.white_background (model_utils.py:97-98): rgb + (1 - acc), coarse and fine outputs alike."""
+    fx, fy, cx, cy = O.intrinsics(16, 16)
+    pose = O.camera_pose((0.0, -0.5, -0.77, 0.0, -90.0, 0.0), (0, 0, 0, -30.0, 0.0, 0.0))[0].numpy()
+    kw = dict(fx=fx, fy=fy, cx=cx, cy=cy, near=0.1, far=10.0, outputs=("rgb", "acc", "rgb_coarse", "acc_coarse"))
+    plain = r_c1.render(pose, 16, 16, **kw)
+    r_c1.set_white_background(True)
+    try:
+        white = r_c1.render(pose, 16, 16, **kw)
+    finally:
+        r_c1.set_white_background(False)
+    for rgb, acc in (("rgb", "acc"), ("rgb_coarse", "acc_coarse")):
+        assert torch.equal(white[acc], plain[acc])
+        assert torch.equal(white[rgb], plain[rgb] + (1.0 - plain[acc])[..., None])
+    assert torch.equal(r_c1.render(pose, 16, 16, **kw)["rgb"], plain["rgb"])
