@@ -163,6 +163,11 @@ int nwe_set_white_background(nwe_ctx *ctx, int on);
 int nwe_set_train_tables(nwe_ctx *ctx, const float *t_rand_dev, const float *noise_coarse_dev, const float *noise_fine_dev,
                          const float *u_sorted_dev);
 
+/* Test hook: the MFMA kernel has two work decompositions with bit-identical results (four ray packets per workgroup, or
+ * one packet whose samples are dealt to the four waves) and picks by frame size; mode 0 / 1 forces one, -1 restores the
+ * automatic choice. */
+int nwe_debug_set_decomposition(nwe_ctx *ctx, int mode);
+
 /* Device self-test of the hardware assumptions the MFMA kernel relies on (fragment layouts of
  * v_mfma_f32_32x32x16_f16, fp16 subnormal operands, LDS-DMA lane order).  report[0..7] receives
  * mismatch counts / measured values; returns NWE_OK when every assumption holds. */

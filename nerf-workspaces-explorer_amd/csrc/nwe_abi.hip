@@ -44,6 +44,7 @@ struct nwe_ctx {
     bool timed = false;
     const float* dbg_z_fine = nullptr;
     int white_bkgd = 0;
+    int decomposition = -1;   // nwe_debug_set_decomposition
     const float *trn_t = nullptr, *trn_nc = nullptr, *trn_nf = nullptr, *trn_u = nullptr;   // nwe_set_train_tables, one call
     std::string err;
 };
@@ -247,7 +248,7 @@ int launch(nwe_ctx* ctx, RenderArgs& a, int precision, void* stream_) {
     if (precision == NWE_PREC_F32) {
         launch_render_f32(a, ctx->net[0].f32, ctx->net[ctx->ni > 0 ? 1 : 0].f32, stream);
     } else {
-        if (!launch_render_mfma(a, ctx->net[0].mf, ctx->net[ctx->ni > 0 ? 1 : 0].mf, precision == NWE_PREC_F16X3, stream))
+        if (!launch_render_mfma(a, ctx->net[0].mf, ctx->net[ctx->ni > 0 ? 1 : 0].mf, precision == NWE_PREC_F16X3, ctx->decomposition, stream))
             return fail(ctx, NWE_ERR_UNSUPPORTED, "coarse and fine networks must have the same shape for the MFMA kernel");
     }
     HIPCHK(ctx, hipGetLastError());
@@ -464,6 +465,12 @@ float nwe_packed_scale(const nwe_ctx* c, int which) {
 int nwe_debug_set_fine_depths(nwe_ctx* c, const float* z_dev) {
     if (!c) return NWE_ERR_INVALID;
     c->dbg_z_fine = z_dev;
+    return NWE_OK;
+}
+
+int nwe_debug_set_decomposition(nwe_ctx* c, int mode) {
+    if (!c || mode < -1 || mode > 1) return NWE_ERR_INVALID;
+    c->decomposition = mode;
     return NWE_OK;
 }
 

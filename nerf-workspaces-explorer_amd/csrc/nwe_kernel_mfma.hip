@@ -928,7 +928,7 @@ bool mfma_supported(int D, int W, int in_xyz, int in_dir, int skip) {
 int mfma_max_samples() { return kMfmaMaxSamples; }
 
 template <int W, int D, int SKIP>
-static void launch_t(const RenderArgs& a, const NetMfma& nc, const NetMfma& nf, bool three_pass, hipStream_t stream) {
+static void launch_t(const RenderArgs& a, const NetMfma& nc, const NetMfma& nf, bool three_pass, int decomposition, hipStream_t stream) {
     // Pick the decomposition that needs fewer sample iterations on the busiest CU (one workgroup per CU at a time).
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
@@ -940,7 +940,7 @@ static void launch_t(const RenderArgs& a, const NetMfma& nc, const NetMfma& nf, 
     const double t_packet = (double)((wg_packet + cus - 1) / cus) * (double)its;
     const double t_split = (double)((wg_split + cus - 1) / cus) * (double)its_split * 1.06;   // redundant sequential part + exchange (measured 5-7 %)
     bool split = t_split < t_packet;
-    if (const char* e = getenv("NWE_SPLIT")) split = e[0] == '1';   // tests force either decomposition
+    if (decomposition >= 0) split = decomposition == 1;   // nwe_debug_set_decomposition: tests force either one
     const unsigned blocks = (unsigned)(split ? wg_split : wg_packet);
     if (three_pass) {
         if (split) hipLaunchKernelGGL((render_mfma_kernel<W, D, SKIP, true, true>), dim3(blocks), dim3(256), 0, stream, a, nc, nf);
@@ -951,11 +951,11 @@ static void launch_t(const RenderArgs& a, const NetMfma& nc, const NetMfma& nf, 
     }
 }
 
-bool launch_render_mfma(const RenderArgs& a, const NetMfma& nc, const NetMfma& nf, bool three_pass, hipStream_t stream) {
+bool launch_render_mfma(const RenderArgs& a, const NetMfma& nc, const NetMfma& nf, bool three_pass, int decomposition, hipStream_t stream) {
     if (a.n_importance > 0 && (nf.D != nc.D || nf.W != nc.W || nf.skip != nc.skip)) return false;
     if (a.n_samples > kMfmaMaxSamples) return false;
-    if (nc.D == 8 && nc.W == 256 && nc.skip == 4) launch_t<256, 8, 4>(a, nc, nf, three_pass, stream);
-    else if (nc.D == 4 && nc.W == 128 && nc.skip == -1) launch_t<128, 4, -1>(a, nc, nf, three_pass, stream);
+    if (nc.D == 8 && nc.W == 256 && nc.skip == 4) launch_t<256, 8, 4>(a, nc, nf, three_pass, decomposition, stream);
+    else if (nc.D == 4 && nc.W == 128 && nc.skip == -1) launch_t<128, 4, -1>(a, nc, nf, three_pass, decomposition, stream);
     else return false;
     return true;
 }

@@ -216,6 +216,10 @@ class Renderer:
             res["_keepalive_depths"] = debug_fine_depths
         return res
 
+    def debug_set_decomposition(self, mode: int) -> None:
+        """Test hook: 0 = four ray packets per workgroup, 1 = sample split, -1 = automatic (bit-identical results)."""
+        self._check(self._lib.nwe_debug_set_decomposition(self._ctx, int(mode)), "nwe_debug_set_decomposition")
+
     def set_white_background(self, on: bool) -> None:
         """rendering.white_background (model_utils.py:97-98): rgb += 1 - acc on every rgb output."""
         self._check(self._lib.nwe_set_white_background(self._ctx, 1 if on else 0), "nwe_set_white_background")

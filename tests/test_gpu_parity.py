@@ -445,7 +445,7 @@ def test_frame_hand_off_and_preview():
 
 
 @pytest.mark.gpu
-def test_work_decompositions_are_bit_identical(monkeypatch):
+def test_work_decompositions_are_bit_identical():
     """The MFMA kernel has two work decompositions (nwe_kernel_mfma.hip: four ray packets per workgroup, or one packet
     whose samples are dealt to the four waves); the launcher picks by frame size.  Same arithmetic in the same order:
     every output must agree bit for bit, including ragged ray counts and sample counts that are no multiple of four."""
@@ -463,19 +463,19 @@ def test_work_decompositions_are_bit_identical(monkeypatch):
         outs = tuple(n for n in names if ni or n in ("rgb", "depth", "acc", "disp", "raw_coarse"))
         res = {}
         for mode in ("0", "1"):
-            monkeypatch.setenv("NWE_SPLIT", mode)
+            r.debug_set_decomposition(int(mode))
             for prec in ("f16x3", "f16x1"):
                 res[mode, prec] = r.render(pose, H, W, fx=fx, fy=fy, cx=cx, cy=cy, near=0.1, far=10.0, precision=prec, outputs=outs)
         for prec in ("f16x3", "f16x1"):
             for k in outs:
                 a, b = res["0", prec][k], res["1", prec][k]
                 assert torch.equal(torch.nan_to_num(a, nan=-7.0), torch.nan_to_num(b, nan=-7.0)), (D, Wn, ns, ni, prec, k)
-    monkeypatch.delenv("NWE_SPLIT")
+        r.close()
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("precision", ["f32", "f16x3"])
-def test_training_mode_forward(golden_dir, precision, monkeypatch):
+def test_training_mode_forward(golden_dir, precision):
     """SURVEY 8 f4, forward only: stratified jitter (training_handler.py:553-562), sigma noise (model_utils.py:64-71)
     and sample_pdf(det=False) (rays.py:98) on host-drawn random numbers (nwe_set_train_tables), against the oracle's
     training-mode golden (its noise / random-u building blocks are pinned against the reference, the jitter lines are a
@@ -492,9 +492,9 @@ def test_training_mode_forward(golden_dir, precision, monkeypatch):
     outs = ("rgb", "depth", "acc", "z_std", "rgb_coarse", "depth_coarse", "acc_coarse", "z_fine", "sample_cond")
     res = {}
     for mode in (("0", "1") if precision != "f32" else ("0",)):
-        monkeypatch.setenv("NWE_SPLIT", mode)
+        r.debug_set_decomposition(int(mode))
         res[mode] = r.render_rays(rays, precision=precision, outputs=outs, train=tr)
-    monkeypatch.delenv("NWE_SPLIT")
+    r.debug_set_decomposition(-1)
     out = res["0"]
     if "1" in res:
         for k in outs:

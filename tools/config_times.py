@@ -13,6 +13,8 @@ for name, H, W, ns, ni, D, Wn in cases:
     if ni:
         r.set_network(1, nwe_amd.synthetic.make_state_dict(1001, D, Wn))
     r.set_sampling(ns, ni)
+    if os.environ.get("NWE_SPLIT"):
+        r.debug_set_decomposition(int(os.environ["NWE_SPLIT"]))
     fx, fy, cx, cy = nwe_amd.pinhole_intrinsics(H, W)
     row = [name]
     for prec in ("f16x3", "f16x1"):
