@@ -33,6 +33,7 @@ if ROOT not in sys.path:
 
 H = W = 800
 NS, NI = 64, 128
+POWER_CAPPED_F16_TFLOPS = 1650.0   # measured on this pool, see profiles/r01_ubench_mfma_power.txt
 PEAK_F16_TFLOPS = 2500.0   # dense fp16/bf16 MFMA peak, MI355X_MICROARCH.md
 # HBM-side bytes of one C3-frame launch from rocprofv3 PMC passes (profiles/r01_pmc_traffic.txt): 2 x FETCH_SIZE (gfx950
 # reports half of a 16-B-per-lane stream) + WRITE_SIZE; L2 misses of the 3.1 TB weight stream, not a bound (21 GB/s).
@@ -154,7 +155,11 @@ def main() -> None:
                                          "not measured in this run; algorithmic 1.76e7 B",
                          "kernel": "render_mfma_kernel<256,8,4>" if args.precision != "f32" else "render_f32_kernel",
                          "kernel_ms": k_ms, "algorithmic_flops_per_launch": flops_per_launch,
-                         "executed_mfma_passes": passes, "frac_executed": achieved * passes / PEAK_F16_TFLOPS},
+                         "executed_mfma_passes": passes, "frac_executed": achieved * passes / PEAK_F16_TFLOPS,
+                         # what a bare dependent chain of this MFMA sustains on RANDOM operands under the socket power cap
+                         # (tools/ubench/mfma_power.hip, profiles/r01_ubench_mfma_power.txt: 1.57-1.75 GHz at ~1300 W)
+                         "power_capped_mfma_peak": POWER_CAPPED_F16_TFLOPS,
+                         "frac_executed_of_power_capped_peak": achieved * passes / POWER_CAPPED_F16_TFLOPS},
         }
         if world == 1 and not args.no_cpu_baseline:
             rays, ref, dt, start = cpu_baseline(sd_c, sd_f, poses[0])
