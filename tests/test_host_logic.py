@@ -28,6 +28,20 @@ def test_config_keys_and_products():
     assert not issubclass(config.ConfigError, Exception)            # BaseException, like config_parser.py:5
     for office in ("office_new_york", "office_geneve", "office_belgrade"):
         assert config.Config.for_office(office).get_param(("model", "net_width"), int) == 256
+    with pytest.raises(FileNotFoundError):
+        config.Config.for_office("office_nowhere")
+
+
+def test_config_reads_a_maintainers_yaml_directory(tmp_path, monkeypatch):
+    """The reference's layout nerf/configs/<office>_config.yaml, given by argument or NWE_CONFIG_DIR, wins over the built-in
+    values; products stay strings until parse_product (no eval)."""
+    (tmp_path / "office_tokyo_config.yaml").write_text(
+        "experiment:\n  image_width: 64\n  image_height: 48\nrendering:\n  n_samples: 32\n  n_rays: 32*32*1\n")
+    cfg = config.Config.for_office("office_tokyo", config_dir=str(tmp_path))
+    assert cfg.get_param(("experiment", "image_width"), int) == 64 and cfg.get_param(("rendering", "n_samples"), int) == 32
+    assert config.parse_product(cfg.get_param(("rendering", "n_rays"), str)) == 1024
+    monkeypatch.setenv("NWE_CONFIG_DIR", str(tmp_path))
+    assert config.Config.for_office("office_tokyo").get_param(("experiment", "image_height"), int) == 48
 
 
 def test_intrinsics_match_handler():
