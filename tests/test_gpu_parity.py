@@ -536,3 +536,23 @@ def test_white_background(r_c1):
         assert torch.equal(white[acc], plain[acc])
         assert torch.equal(white[rgb], plain[rgb] + (1.0 - plain[acc])[..., None])
     assert torch.equal(r_c1.render(pose, 16, 16, **kw)["rgb"], plain["rgb"])
+
+
+@pytest.mark.gpu
+def test_repeated_renders_are_bit_identical(r_c3):
+    """The weight stream is double-buffered through LDS with one barrier per tile and a deliberately relaxed wait in front of
+    it (Walker::sync): any race between a late fragment read and the next chunk's DMA would show up as run-to-run
+    differences.  Five renders of a frame that fills every CU several times over, both decompositions, every bit equal."""
+    fx, fy, cx, cy = O.intrinsics(256, 512)
+    pose = O.camera_pose((0.0, -0.5, -0.77, 0.0, -90.0, 0.0), (0, 0, 0, -30.0, 0.0, 0.0))[0].numpy()
+    kw = dict(fx=fx, fy=fy, cx=cx, cy=cy, near=0.1, far=10.0, outputs=("rgb", "depth", "acc", "rgb_coarse"))
+    first = None
+    for mode in (0, 1):
+        r_c3.debug_set_decomposition(mode)
+        for _ in range(5 if mode == 0 else 2):
+            out = r_c3.render(pose, 256, 512, **kw)
+            if first is None:
+                first = {k: v.clone() for k, v in out.items()}
+            for k in kw["outputs"]:
+                assert torch.equal(out[k], first[k]), (mode, k)
+    r_c3.debug_set_decomposition(-1)
