@@ -556,3 +556,39 @@ def test_repeated_renders_are_bit_identical(r_c3):
             for k in kw["outputs"]:
                 assert torch.equal(out[k], first[k]), (mode, k)
     r_c3.debug_set_decomposition(-1)
+
+
+@pytest.mark.gpu
+def test_randomised_sampling_configurations_against_live_oracle():
+    """Edge geometry the fixed goldens do not reach: odd and tiny sample counts (Ns=3 is the smallest sample_pdf accepts,
+    rays.py:87), Ni > Ns, Ni = 1, non-unit ray directions, near/far other than the YAML's, a ragged ray count; MFMA path
+    against the oracle run live on the same rays (thin-fog coarse net: well-conditioned sampling, every ray compared)."""
+    rng = np.random.default_rng(20240)
+    sd_c = nwe_amd.synthetic.thin_fog(_sd(1000, 8, 256))
+    sd_f = _sd(1001, 8, 256)
+    r = nwe_amd.Renderer(0)
+    r.set_network(0, sd_c)
+    r.set_network(1, sd_f)
+    for ns, ni, near, far, n_rays in [(3, 5, 0.1, 10.0, 70), (5, 1, 0.5, 4.0, 33), (64, 256, 0.1, 10.0, 45), (17, 40, 0.05, 6.0, 129),
+                                      (33, 2, 1.0, 2.0, 64), (64, 0, 0.1, 10.0, 50), (4, 0, 0.1, 10.0, 31)]:
+        r.set_sampling(ns, ni)
+        o = rng.uniform(-1.0, 1.0, (n_rays, 3)).astype(np.float32)
+        d = (rng.normal(size=(n_rays, 3)) * rng.uniform(0.2, 3.0, (n_rays, 1))).astype(np.float32)   # |d| from 0.2 to ~5
+        v = d / np.linalg.norm(d, axis=1, keepdims=True)
+        rays = torch.from_numpy(np.concatenate([o, d, np.full((n_rays, 1), near, np.float32), np.full((n_rays, 1), far, np.float32),
+                                                v.astype(np.float32)], 1))
+        ref = O.render_rays(rays, _t(sd_c), _t(sd_f) if ni else None, O.RenderConfig(n_samples=ns, n_importance=ni))
+        for mode in (0, 1):
+            r.debug_set_decomposition(mode)
+            outs = ("rgb", "depth", "acc") + (("z_fine", "z_std") if ni else ())
+            got = r.render_rays(rays.cuda(), precision="f16x3", outputs=outs)
+            key = "fine" if ni else "coarse"
+            last = ref["raw_" + key][:, -1, 3].abs().numpy()
+            ok = last > 1e-5
+            err = np.abs(got["rgb"].cpu().numpy() - ref["rgb_" + key].numpy())[ok].max()
+            derr = np.abs(got["depth"].cpu().numpy() - ref["depth_" + key].numpy())[ok].max() / far
+            assert err <= RGB_TOL and derr <= 1e-4, (ns, ni, mode, err, derr)
+            if ni:
+                assert np.abs(got["z_fine"].cpu().numpy() - ref["z_fine"].numpy()).max() <= 1e-4 * far, (ns, ni, mode)
+                assert np.abs(got["z_std"].cpu().numpy() - ref["z_std"].numpy()).max() <= 1e-4 * far, (ns, ni, mode)
+    r.close()
