@@ -67,6 +67,11 @@ class Workspace:
         return self._name
 
     @property
+    def folder_path(self) -> str:
+        """application/workspaces/<office> under the project root (floor-plan images of the GUI, workspace.py:23-24,39)."""
+        return os.path.normpath(os.path.join(os.getcwd(), "application", "workspaces", self._office_name))
+
+    @property
     def floor_plan_scale(self) -> HW:
         return OFFICES[self._name].floor_plan_scale
 
@@ -80,6 +85,29 @@ class Workspace:
     def transform_relative_coordinates(self, rel_x: float, rel_y: float, hor_angle: float, ver_angle: float) -> Tuple[COORD, COORD]:
         return click_to_coordinates(self._name, rel_x, rel_y, hor_angle, ver_angle)
 
+    _transform_relative_coordinates = transform_relative_coordinates   # the reference's (private) name, workspace.py:47
+
     def render_image(self, rel_x: float, rel_y: float, horizontal_angle: int, vertical_angle: int) -> np.ndarray:
         init_coordinates, coordinates = self.transform_relative_coordinates(rel_x, rel_y, horizontal_angle, vertical_angle)
         return self._nerf_inference.render_coordinates(init_coordinates, coordinates)   # H, W, C uint8
+
+
+# The four concrete workspaces application/app.py:12-15 instantiates without arguments (workspace.py:71,103,135,167).
+class OfficeTokyoWorkspace(Workspace):
+    def __init__(self, **kw) -> None:
+        super().__init__("Office Tokyo", **kw)
+
+
+class OfficeNewYorkWorkspace(Workspace):
+    def __init__(self, **kw) -> None:
+        super().__init__("Office New York", **kw)
+
+
+class OfficeGeneveWorkspace(Workspace):
+    def __init__(self, **kw) -> None:
+        super().__init__("Office Geneve", **kw)
+
+
+class OfficeBelgradeWorkspace(Workspace):
+    def __init__(self, **kw) -> None:
+        super().__init__("Office Belgrade", **kw)

@@ -131,3 +131,13 @@ def test_workspace_click_maps():
         ws.initialize_models()
     with pytest.raises(KeyError):
         nwe_amd.Workspace("Office Paris")
+
+
+def test_concrete_workspace_classes():
+    """application/app.py:12-15 builds the four workspaces without arguments; same names, same surface."""
+    for cls, name, scale in ((nwe_amd.OfficeTokyoWorkspace, "Office Tokyo", (600, 600)), (nwe_amd.OfficeNewYorkWorkspace, "Office New York", (600, 800)),
+                             (nwe_amd.OfficeGeneveWorkspace, "Office Geneve", (600, 1000)), (nwe_amd.OfficeBelgradeWorkspace, "Office Belgrade", (600, 750))):
+        ws = cls()
+        assert isinstance(ws, nwe_amd.Workspace) and ws.name == name and tuple(ws.floor_plan_scale) == scale
+        assert ws.folder_path.endswith(os.path.join("application", "workspaces", name.replace(" ", "_").lower()))
+        assert ws._transform_relative_coordinates(0.5, 0.5, 30, 0) == nwe_amd.click_to_coordinates(name, 0.5, 0.5, 30, 0)
