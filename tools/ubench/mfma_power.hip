@@ -29,12 +29,20 @@ __global__ __launch_bounds__(256, 1) void k(float* out, const h8* src, int iters
 
 int main(int argc, char** argv) {
     const bool zeros = argc > 1 && atoi(argv[1]) == 0;
+    const int keep_a = argc > 2 ? atoi(argv[2]) : 10, keep_b = argc > 3 ? atoi(argv[3]) : 10;   // mantissa bits kept in the A / B operands
     const int nblk = 256, iters = 20000;   // 48 * 20000 MFMAs per launch = ~15 ms
     float* out; h8* src; unsigned long long* cyc;
     (void)hipMalloc(&out, nblk * 256 * 4); (void)hipMalloc(&src, 1024 * 16); (void)hipMalloc(&cyc, nblk * 8);
     std::vector<_Float16> h(1024 * 8);
     srand(1);
     for (auto& v : h) v = zeros ? (_Float16)0.f : (_Float16)((rand() / (float)RAND_MAX - 0.5f) * 0.01f);
+    {   // operand values 0..511 feed A (a[i] = src[lane + 64 i], i < 4 -> h8 index < 256... A uses h8 0..255, B uses 256..511)
+        unsigned short* u = reinterpret_cast<unsigned short*>(h.data());
+        for (size_t i = 0; i < h.size(); ++i) {
+            const int keep = (i / 8) % 512 < 256 ? keep_a : keep_b;
+            u[i] &= (unsigned short)(0xFFFFu << (10 - keep));
+        }
+    }
     (void)hipMemcpy(src, h.data(), h.size() * 2, hipMemcpyHostToDevice);
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
@@ -46,7 +54,7 @@ int main(int argc, char** argv) {
         float ms; (void)hipEventElapsedTime(&ms, e0, e1);
         unsigned long long c; (void)hipMemcpy(&c, cyc, 8, hipMemcpyDeviceToHost);
         const double n = 48.0 * iters;
-        printf("%s operands: %.2f cycles/MFMA, %.2f ns/MFMA -> %.0f MHz, %.0f TFLOP/s\n", zeros ? "zero" : "random", c / n, ms * 1e6 / 30 / n,
+        printf("%s operands (mantissa bits A %d, B %d): %.2f cycles/MFMA, %.2f ns/MFMA -> %.0f MHz, %.0f TFLOP/s\n", zeros ? "zero" : "random", keep_a, keep_b, c / n, ms * 1e6 / 30 / n,
                (c / n) / (ms * 1e6 / 30 / n) * 1e3, 1024.0 * 32768.0 / (ms * 1e6 / 30 / n) / 1e3);
         fflush(stdout);
     }

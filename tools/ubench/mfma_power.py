@@ -10,9 +10,10 @@ def sampler():
             samples.append((time.time(), "err", str(e)))
         time.sleep(0.3)
 th = threading.Thread(target=sampler, daemon=True); th.start()
-for mode in ("0", "1"):
+runs = [["0"], ["1"]] + [["1"] + a for a in sys.argv[1:] and [x.split(",") for x in sys.argv[1:]]]
+for mode in runs:
     t0 = time.time()
-    p = subprocess.run(["/tmp/mfma_power", mode], capture_output=True, text=True)
+    p = subprocess.run(["/tmp/mfma_power"] + mode, capture_output=True, text=True)
     t1 = time.time()
     print(p.stdout.strip().splitlines()[-1])
     print("   rocm-smi:", [(s[1], s[2]) for s in samples if t0 + 1.0 < s[0] < t1][-6:])
