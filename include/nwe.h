@@ -168,6 +168,10 @@ int nwe_set_train_tables(nwe_ctx *ctx, const float *t_rand_dev, const float *noi
  * automatic choice. */
 int nwe_debug_set_decomposition(nwe_ctx *ctx, int mode);
 
+/* Diagnostic builds only (make -C csrc stamps): DEVICE buffer of 8 uint64 per wave that a -DNWE_STAMPS build of the MFMA
+ * kernel fills with s_memtime cycle sums (tools/stamp_run.py); the product build never touches it.  NULL switches it off. */
+int nwe_debug_set_stamps(nwe_ctx *ctx, unsigned long long *per_wave_dev);
+
 /* Device self-test of the hardware assumptions the MFMA kernel relies on (fragment layouts of
  * v_mfma_f32_32x32x16_f16, fp16 subnormal operands, LDS-DMA lane order).  report[0..7] receives
  * mismatch counts / measured values; returns NWE_OK when every assumption holds. */

@@ -45,6 +45,7 @@ struct nwe_ctx {
     const float* dbg_z_fine = nullptr;
     int white_bkgd = 0;
     int decomposition = -1;   // nwe_debug_set_decomposition
+    unsigned long long* stamps = nullptr;   // nwe_debug_set_stamps
     const float *trn_t = nullptr, *trn_nc = nullptr, *trn_nf = nullptr, *trn_u = nullptr;   // nwe_set_train_tables, one call
     std::string err;
 };
@@ -239,10 +240,7 @@ int launch(nwe_ctx* ctx, RenderArgs& a, int precision, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     a.t_vals = ctx->d_t; a.omt_vals = ctx->d_omt; a.u_vals = ctx->d_u;
     a.n_samples = ctx->ns; a.n_importance = ctx->ni;
-    {   // diagnostic builds: NWE_STAMPS_PTR carries a device pointer (decimal) to per-wave cycle sums
-        const char* e = getenv("NWE_STAMPS_PTR");
-        a.stamps = e ? reinterpret_cast<unsigned long long*>(strtoull(e, nullptr, 10)) : nullptr;
-    }
+    a.stamps = ctx->stamps;   // only read by -DNWE_STAMPS builds of the kernel (nwe_debug_set_stamps)
     if (a.n_rays <= 0) return NWE_OK;
     HIPCHK(ctx, hipEventRecord(ctx->ev0, stream));
     if (precision == NWE_PREC_F32) {
@@ -471,6 +469,12 @@ int nwe_debug_set_fine_depths(nwe_ctx* c, const float* z_dev) {
 int nwe_debug_set_decomposition(nwe_ctx* c, int mode) {
     if (!c || mode < -1 || mode > 1) return NWE_ERR_INVALID;
     c->decomposition = mode;
+    return NWE_OK;
+}
+
+int nwe_debug_set_stamps(nwe_ctx* c, unsigned long long* per_wave_dev) {
+    if (!c) return NWE_ERR_INVALID;
+    c->stamps = per_wave_dev;
     return NWE_OK;
 }
 

@@ -6,9 +6,10 @@ torch.cuda.init()
 H, W = 128, 256
 nw = H * W // 32
 buf = torch.zeros(nw * 8, dtype=torch.int64, device="cuda")
-os.environ["NWE_STAMPS_PTR"] = str(buf.data_ptr())
 import nwe_amd
 r = nwe_amd.Renderer(0)
+r._lib.nwe_debug_set_stamps(r._ctx, buf.data_ptr())
+r.debug_set_decomposition(0)   # stamps are laid out for four packets per workgroup
 r.set_network(0, nwe_amd.synthetic.make_state_dict(1000, 8, 256)); r.set_network(1, nwe_amd.synthetic.make_state_dict(1001, 8, 256))
 r.set_sampling(64, 128)
 fx, fy, cx, cy = nwe_amd.pinhole_intrinsics(H, W)
