@@ -51,11 +51,14 @@ def gather_tiles(tile: torch.Tensor, H: int, rank: int, world: int, dst: int = 0
     if h < h_max:
         send = torch.zeros((B, h_max, W, C), dtype=tile.dtype, device=tile.device)
         send[:, :h] = tile
+    device = tile.device
+    if dist.get_backend(group) == "gloo" and send.is_cuda:
+        send = send.cpu()        # gloo gathers host tensors (CPU tests, several ranks sharing one GPU); nccl = RCCL stays on device
     bufs = [torch.empty_like(send) for _ in range(world)] if rank == dst else None
     dist.gather(send, bufs, dst=dst, group=group)
     if rank != dst:
         return None
-    return torch.cat([bufs[r][:, : ranges[r][1] - ranges[r][0]] for r in range(world)], dim=1)
+    return torch.cat([bufs[r][:, : ranges[r][1] - ranges[r][0]] for r in range(world)], dim=1).to(device)
 
 
 class TileShardedRenderer:
