@@ -245,7 +245,7 @@ __device__ __forceinline__ void mma3(const h8& a_hi, const h8& a_lo, const h8& x
 //     earlier).  After it (a) chunk T+1 is visible, so the A fragments of tile T+1's first PD k-steps are read
 //     during the last PD k-steps of tile T and the matrix pipe does not drain at the tile boundary, and (b) buffer
 //     T&1 is free, so the DMA of chunk T+2 starts at once: its first PD pieces in tile T, the rest early in T+1.
-template <int CHUNK_BYTES>
+template <int CHUNK_BYTES, bool X3>
 struct Walker {
     const uint8_t* stream;
     uint32_t next_tile;      // first tile of the next chunk to stream
@@ -258,6 +258,7 @@ struct Walker {
     uint32_t lane_off;       // lane * 16
     const uint8_t* blk_src;  // this wave's quarter of the chunk being streamed (uniform)
     uint32_t blk_dst;
+    bool skip_lo = false;    // single-pass mode: the odd pieces of the chunk being streamed are lo tiles
 #ifdef NWE_STAMPS
     unsigned long long st_pre = 0, st_wait = 0, st_post = 0, st_t0 = 0;
 #endif
@@ -271,6 +272,7 @@ struct Walker {
         blk_src = stream + ((size_t)next_tile + (size_t)wave * n_per_wave) * kTileBytes;
         blk_dst = lds_chunks + buffer * CHUNK_BYTES + wave * n_per_wave * kTileBytes;
         next_tile += n_per_wave * kWaves;
+        skip_lo = !X3 && (n_per_wave & 1) == 0;
     }
     // Piece i of the chunk being streamed.  Pieces go in groups of four: one scalar base per group, the 1-KiB step inside
     // a group rides on the instruction offset, which advances the global source AND the LDS destination (nwe_selftest
@@ -279,6 +281,10 @@ struct Walker {
 #ifdef NWE_EXP_NODMA   // timing experiments only; a run-time test here would split every k-step into its own basic block
         return;
 #endif
+        // single-pass mode multiplies by the hi tiles only: where a wave's quarter of the chunk starts on an even tile (all
+        // chunks but the view layer's, 9 tiles per wave) the lo tile of every (hi, lo) pair = the odd pieces is neither
+        // streamed nor read; the LDS layout keeps its holes.  (A run-time test, but only in the single-pass instantiation.)
+        if (!X3 && skip_lo && (i & 1)) return;
         const uint8_t* src = blk_src + (size_t)(i >> 2) * (4 * kTileBytes);
         const uint32_t dst = blk_dst + (i >> 2) * (4 * kTileBytes);
         switch (i & 3) {
@@ -711,7 +717,7 @@ __global__ void __launch_bounds__(256) render_mfma_kernel(RenderArgs a, NetMfma 
     const int64_t rclamp = ridx < a.n_rays ? ridx : a.n_rays - 1;
     const Ray ray = load_ray(a, rclamp);
 
-    Walker<S::CHUNK_BYTES> wk;
+    Walker<S::CHUNK_BYTES, X3> wk;
     wk.buf0 = smem; wk.lds_chunks = (uint32_t)(uintptr_t)(LDS_AS char*)smem;
     wk.b = 0; wk.wave = wave; wk.lane_off = lane * 16;
 
