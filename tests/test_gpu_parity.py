@@ -592,3 +592,23 @@ def test_randomised_sampling_configurations_against_live_oracle():
                 assert np.abs(got["z_fine"].cpu().numpy() - ref["z_fine"].numpy()).max() <= 1e-4 * far, (ns, ni, mode)
                 assert np.abs(got["z_std"].cpu().numpy() - ref["z_std"].numpy()).max() <= 1e-4 * far, (ns, ni, mode)
     r.close()
+
+
+@pytest.mark.gpu
+def test_contexts_and_streams_are_independent(r_c1, r_c3):
+    """Two contexts with different networks interleaved, and a launch on a non-default torch stream: each result equals
+    the one the context produces on its own on the default stream (a context owns its weights, tables and scratch)."""
+    fx, fy, cx, cy = O.intrinsics(24, 32)
+    pose = O.camera_pose((0.0, -0.5, -0.77, 0.0, -90.0, 0.0), (0, 0, 0, -30.0, 0.0, 0.0))[0].numpy()
+    kw = dict(fx=fx, fy=fy, cx=cx, cy=cy, near=0.1, far=10.0, outputs=("rgb", "depth"))
+    a0 = r_c1.render(pose, 24, 32, **kw)
+    b0 = r_c3.render(pose, 24, 32, **kw)
+    side = torch.cuda.Stream()
+    for _ in range(3):
+        with torch.cuda.stream(side):
+            a = r_c1.render(pose, 24, 32, **kw)
+        b = r_c3.render(pose, 24, 32, **kw)
+        side.synchronize()
+        torch.cuda.synchronize()
+        assert torch.equal(a["rgb"], a0["rgb"]) and torch.equal(a["depth"], a0["depth"])
+        assert torch.equal(b["rgb"], b0["rgb"]) and torch.equal(b["depth"], b0["depth"])
