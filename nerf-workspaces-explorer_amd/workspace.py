@@ -87,9 +87,11 @@ class Workspace:
 
     _transform_relative_coordinates = transform_relative_coordinates   # the reference's (private) name, workspace.py:47
 
-    def render_image(self, rel_x: float, rel_y: float, horizontal_angle: int, vertical_angle: int) -> np.ndarray:
+    def render_image(self, rel_x: float, rel_y: float, horizontal_angle: int, vertical_angle: int, *,
+                     out: Optional[np.ndarray] = None, preview: bool = False) -> np.ndarray:
+        """workspace.py:54-68 (without the console print).  ``out`` / ``preview``: see NeRFReplicaInferenceHandler.render_coordinates."""
         init_coordinates, coordinates = self.transform_relative_coordinates(rel_x, rel_y, horizontal_angle, vertical_angle)
-        return self._nerf_inference.render_coordinates(init_coordinates, coordinates)   # H, W, C uint8
+        return self._nerf_inference.render_coordinates(init_coordinates, coordinates, out=out, preview=preview)   # H, W, C uint8
 
 
 # The four concrete workspaces application/app.py:12-15 instantiates without arguments (workspace.py:71,103,135,167).
