@@ -33,6 +33,7 @@ if ROOT not in sys.path:
 
 H = W = 800
 NS, NI = 64, 128
+LIBRARY_GEMM_F16_TFLOPS = 1330.0   # measured on this pool, tools/gemm_reference.py
 POWER_CAPPED_F16_TFLOPS = 1650.0   # measured on this pool, see profiles/r01_ubench_mfma_power.txt
 PEAK_F16_TFLOPS = 2500.0   # dense fp16/bf16 MFMA peak, MI355X_MICROARCH.md
 # HBM-side bytes of one C3-frame launch from rocprofv3 PMC passes (profiles/r01_pmc_traffic.txt): 2 x FETCH_SIZE (gfx950
@@ -159,7 +160,9 @@ def main() -> None:
                          # what a bare dependent chain of this MFMA sustains on RANDOM operands under the socket power cap
                          # (tools/ubench/mfma_power.hip, profiles/r01_ubench_mfma_power.txt: 1.57-1.75 GHz at ~1300 W)
                          "power_capped_mfma_peak": POWER_CAPPED_F16_TFLOPS,
-                         "frac_executed_of_power_capped_peak": achieved * passes / POWER_CAPPED_F16_TFLOPS},
+                         "frac_executed_of_power_capped_peak": achieved * passes / POWER_CAPPED_F16_TFLOPS,
+                         # torch.matmul (hipBLASLt) fp16 8192^3 on random operands, same pool (profiles/r01_gemm_reference.txt)
+                         "library_gemm_f16_sustained": LIBRARY_GEMM_F16_TFLOPS},
         }
         if world == 1 and not args.no_cpu_baseline:
             rays, ref, dt, start = cpu_baseline(sd_c, sd_f, poses[0])
