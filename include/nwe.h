@@ -164,8 +164,9 @@ int nwe_set_train_tables(nwe_ctx *ctx, const float *t_rand_dev, const float *noi
                          const float *u_sorted_dev);
 
 /* Test hook: the MFMA kernel has two work decompositions with bit-identical results (four ray packets per workgroup, or
- * one packet whose samples are dealt to the four waves) and picks by frame size; mode 0 / 1 forces one, -1 restores the
- * automatic choice. */
+ * one packet whose samples are dealt to the four waves) and picks by frame size - all of one kind, or the full rounds of
+ * workgroups as packets and the ragged last round sample-split in a second launch; mode 0 / 1 / 2 forces a plan, -1
+ * restores the automatic choice. */
 int nwe_debug_set_decomposition(nwe_ctx *ctx, int mode);
 
 /* Diagnostic builds only (make -C csrc stamps): DEVICE buffer of 8 uint64 per wave that a -DNWE_STAMPS build of the MFMA

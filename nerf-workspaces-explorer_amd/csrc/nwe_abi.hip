@@ -467,7 +467,7 @@ int nwe_debug_set_fine_depths(nwe_ctx* c, const float* z_dev) {
 }
 
 int nwe_debug_set_decomposition(nwe_ctx* c, int mode) {
-    if (!c || mode < -1 || mode > 1) return NWE_ERR_INVALID;
+    if (!c || mode < -1 || mode > 2) return NWE_ERR_INVALID;
     c->decomposition = mode;
     return NWE_OK;
 }

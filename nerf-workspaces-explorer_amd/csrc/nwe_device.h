@@ -24,6 +24,7 @@ struct RenderArgs {
     const float* rays;       // device, may be null -> generate from poses
     const float* poses;      // device, n_poses x 16 (row-major c2w)
     int64_t n_rays;          // total rays of the call
+    int64_t ray_first;       // first ray of THIS launch (a call may be split into launches with different decompositions)
     int H, W, row_begin, rows;  // rows = row_end-row_begin; rays per pose = rows*W
     float fx, fy, cx, cy, near, far;
     // sampling tables (device): t[ns], 1-t[ns], u[ni]

@@ -34,7 +34,8 @@ struct NetMfma {
 // true if a kernel instantiation exists for this shape
 bool mfma_supported(int D, int W, int in_xyz, int in_dir, int skip);
 // returns false if the shape has no instantiation.  decomposition: -1 = pick by frame size, 0 = four ray packets per
-// workgroup, 1 = one packet per workgroup with its samples dealt to the four waves (bit-identical results)
+// workgroup, 1 = one packet per workgroup with its samples dealt to the four waves, 2 = full rounds as 0 and the ragged
+// last round as 1 in a second launch (bit-identical results)
 bool launch_render_mfma(const RenderArgs& a, const NetMfma& nc, const NetMfma& nf, bool three_pass, int decomposition, hipStream_t stream);
 
 constexpr int kTileBytes = 1024;

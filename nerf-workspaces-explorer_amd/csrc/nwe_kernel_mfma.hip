@@ -711,7 +711,7 @@ __global__ void __launch_bounds__(256) render_mfma_kernel(RenderArgs a, NetMfma 
     }
 
     const int64_t packet = SPLIT ? (int64_t)blockIdx.x : (int64_t)blockIdx.x * kWaves + wave;
-    const int64_t ridx = packet * kRaysPerWave + (lane & 31);
+    const int64_t ridx = a.ray_first + packet * kRaysPerWave + (lane & 31);
     const bool lane_live = ridx < a.n_rays && half == 0;      // this lane stores per-sample outputs of its ray
     const bool live = lane_live && (!SPLIT || wave == 0);      // ... and the per-ray results (every wave holds them in SPLIT mode)
     const int64_t rclamp = ridx < a.n_rays ? ridx : a.n_rays - 1;
@@ -934,26 +934,46 @@ bool mfma_supported(int D, int W, int in_xyz, int in_dir, int skip) {
 int mfma_max_samples() { return kMfmaMaxSamples; }
 
 template <int W, int D, int SKIP>
-static void launch_t(const RenderArgs& a, const NetMfma& nc, const NetMfma& nf, bool three_pass, int decomposition, hipStream_t stream) {
-    // Pick the decomposition that needs fewer sample iterations on the busiest CU (one workgroup per CU at a time).
-    int dev = 0, cus = 256;
-    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    if (cus <= 0) cus = 256;
-    const int64_t its = a.n_samples + (a.n_importance > 0 ? a.n_samples + a.n_importance : 0);
-    const int64_t its_split = (a.n_samples + 3) / 4 + (a.n_importance > 0 ? (a.n_samples + a.n_importance + 3) / 4 : 0);
-    const int64_t wg_packet = (a.n_rays + kWaves * kRaysPerWave - 1) / (kWaves * kRaysPerWave);
-    const int64_t wg_split = (a.n_rays + kRaysPerWave - 1) / kRaysPerWave;
-    const double t_packet = (double)((wg_packet + cus - 1) / cus) * (double)its;
-    const double t_split = (double)((wg_split + cus - 1) / cus) * (double)its_split * 1.06;   // redundant sequential part + exchange (measured 5-7 %)
-    bool split = t_split < t_packet;
-    if (decomposition >= 0) split = decomposition == 1;   // nwe_debug_set_decomposition: tests force either one
-    const unsigned blocks = (unsigned)(split ? wg_split : wg_packet);
+static void launch_one(RenderArgs a, const NetMfma& nc, const NetMfma& nf, bool three_pass, bool split, int64_t ray_first, int64_t rays,
+                       hipStream_t stream) {
+    if (rays <= 0) return;
+    a.ray_first = ray_first;
+    const int64_t per_wg = split ? kRaysPerWave : kWaves * kRaysPerWave;
+    const unsigned blocks = (unsigned)((rays + per_wg - 1) / per_wg);
     if (three_pass) {
         if (split) hipLaunchKernelGGL((render_mfma_kernel<W, D, SKIP, true, true>), dim3(blocks), dim3(256), 0, stream, a, nc, nf);
         else hipLaunchKernelGGL((render_mfma_kernel<W, D, SKIP, true, false>), dim3(blocks), dim3(256), 0, stream, a, nc, nf);
     } else {
         if (split) hipLaunchKernelGGL((render_mfma_kernel<W, D, SKIP, false, true>), dim3(blocks), dim3(256), 0, stream, a, nc, nf);
         else hipLaunchKernelGGL((render_mfma_kernel<W, D, SKIP, false, false>), dim3(blocks), dim3(256), 0, stream, a, nc, nf);
+    }
+}
+
+template <int W, int D, int SKIP>
+static void launch_t(const RenderArgs& a, const NetMfma& nc, const NetMfma& nf, bool three_pass, int decomposition, hipStream_t stream) {
+    // One workgroup per CU at a time, so a launch costs (rounds of workgroups) x (sample iterations per workgroup).  Three
+    // plans, same arithmetic: all packets; all sample-split (finer units, ~6 % overhead: redundant sequential part and
+    // exchange); or the full rounds as packets and the ragged last round sample-split in a second launch behind it.
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (cus <= 0) cus = 256;
+    const int64_t rays_wg = kWaves * kRaysPerWave;
+    const double its = (double)(a.n_samples + (a.n_importance > 0 ? a.n_samples + a.n_importance : 0));
+    const double its_split = 1.06 * (double)((a.n_samples + 3) / 4 + (a.n_importance > 0 ? (a.n_samples + a.n_importance + 3) / 4 : 0));
+    const auto rounds = [&](int64_t rays, int64_t per_wg) { return (double)(((rays + per_wg - 1) / per_wg + cus - 1) / cus); };
+    const int64_t full = (a.n_rays / rays_wg / cus) * cus * rays_wg;            // rays in complete rounds of packet workgroups
+    const double t_packet = rounds(a.n_rays, rays_wg) * its;
+    const double t_split = rounds(a.n_rays, kRaysPerWave) * its_split;
+    const double t_hybrid = full > 0 && full < a.n_rays ? (double)(full / rays_wg / cus) * its + rounds(a.n_rays - full, kRaysPerWave) * its_split : 1e300;
+    // two launches only when they buy at least 3 % (one launch per frame keeps profiles simple: 800x800 would gain 1 %)
+    const double t_single = t_packet <= t_split ? t_packet : t_split;
+    int plan = t_hybrid < 0.97 * t_single ? 2 : (t_packet <= t_split ? 0 : 1);
+    if (decomposition >= 0) plan = decomposition;   // nwe_debug_set_decomposition: tests force one
+    if (plan == 2) {
+        launch_one<W, D, SKIP>(a, nc, nf, three_pass, false, 0, full, stream);
+        launch_one<W, D, SKIP>(a, nc, nf, three_pass, true, full, a.n_rays - full, stream);
+    } else {
+        launch_one<W, D, SKIP>(a, nc, nf, three_pass, plan == 1, 0, a.n_rays, stream);
     }
 }
 

@@ -217,7 +217,8 @@ class Renderer:
         return res
 
     def debug_set_decomposition(self, mode: int) -> None:
-        """Test hook: 0 = four ray packets per workgroup, 1 = sample split, -1 = automatic (bit-identical results)."""
+        """Test hook: 0 = four ray packets per workgroup, 1 = sample split, 2 = packets for the full rounds + sample split for the
+        ragged last round, -1 = automatic (bit-identical results)."""
         self._check(self._lib.nwe_debug_set_decomposition(self._ctx, int(mode)), "nwe_debug_set_decomposition")
 
     def set_white_background(self, on: bool) -> None:

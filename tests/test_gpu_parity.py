@@ -547,7 +547,7 @@ def test_repeated_renders_are_bit_identical(r_c3):
     pose = O.camera_pose((0.0, -0.5, -0.77, 0.0, -90.0, 0.0), (0, 0, 0, -30.0, 0.0, 0.0))[0].numpy()
     kw = dict(fx=fx, fy=fy, cx=cx, cy=cy, near=0.1, far=10.0, outputs=("rgb", "depth", "acc", "rgb_coarse"))
     first = None
-    for mode in (0, 1):
+    for mode in (0, 1, 2):      # 131072 rays = 4 full rounds of packet workgroups on 256 CUs: plan 2 degenerates to plan 0 here
         r_c3.debug_set_decomposition(mode)
         for _ in range(5 if mode == 0 else 2):
             out = r_c3.render(pose, 256, 512, **kw)
@@ -612,3 +612,26 @@ def test_contexts_and_streams_are_independent(r_c1, r_c3):
         torch.cuda.synchronize()
         assert torch.equal(a["rgb"], a0["rgb"]) and torch.equal(a["depth"], a0["depth"])
         assert torch.equal(b["rgb"], b0["rgb"]) and torch.equal(b["depth"], b0["depth"])
+
+
+@pytest.mark.gpu
+def test_hybrid_launch_plan(r_c3):
+    """A frame with full rounds of 128-ray workgroups plus a ragged rest (300x200 = 60000 rays on 256 CUs: one round of
+    32768 rays as packets, 27232 rays sample-split in a second launch): all three plans give the same bits, and the
+    automatic choice is within 5 % of the fastest of them."""
+    fx, fy, cx, cy = O.intrinsics(200, 300)
+    pose = O.camera_pose((0.0, -0.5, -0.77, 0.0, -90.0, 0.0), (0, 0, 0, -30.0, 0.0, 0.0))[0].numpy()
+    kw = dict(fx=fx, fy=fy, cx=cx, cy=cy, near=0.1, far=10.0, outputs=("rgb", "depth", "acc", "z_std", "rgb_coarse"))
+    res, ms = {}, {}
+    for mode in (0, 1, 2, -1):
+        r_c3.debug_set_decomposition(mode)
+        res[mode] = r_c3.render(pose, 200, 300, **kw)
+        torch.cuda.synchronize()
+        r_c3.render(pose, 200, 300, **kw)
+        ms[mode] = r_c3.last_kernel_ms()
+    r_c3.debug_set_decomposition(-1)
+    for mode in (1, 2, -1):
+        for k in kw["outputs"]:
+            assert torch.equal(res[mode][k], res[0][k]), (mode, k)
+    print("kernel ms by plan (packets, split, hybrid, auto):", [round(ms[m], 2) for m in (0, 1, 2, -1)])
+    assert ms[-1] <= 1.05 * min(ms[0], ms[1], ms[2])
