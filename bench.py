@@ -38,7 +38,7 @@ POWER_CAPPED_F16_TFLOPS = 1650.0   # measured on this pool, see profiles/r01_ube
 PEAK_F16_TFLOPS = 2500.0   # dense fp16/bf16 MFMA peak, MI355X_MICROARCH.md
 # HBM-side bytes of one C3-frame launch from rocprofv3 PMC passes (profiles/r01_pmc_traffic.txt): 2 x FETCH_SIZE (gfx950
 # reports half of a 16-B-per-lane stream) + WRITE_SIZE; L2 misses of the 3.1 TB weight stream, not a bound (21 GB/s).
-TRAFFIC_BYTES_C3_LAUNCH = 1.049e10   # (FETCH_SIZE 5.229e6 KB x 2 + WRITE_SIZE 3.25e4 KB) x 1024, final round-1 kernel: profiles/r01_pmc_traffic.txt
+TRAFFIC_BYTES_C3_LAUNCH = (2 * 5.229e6 + 3.25e4) * 1024   # FETCH_SIZE x 2 (gfx950) + WRITE_SIZE, in KB; final round-1 kernel, profiles/r01_pmc_traffic.txt
 CPU_SAMPLE_RAYS = 8192     # one reference chunk (inference.chunk = 1024*8): ~10 s of CPU work on 8-16 cores
 
 
