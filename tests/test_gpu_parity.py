@@ -635,3 +635,35 @@ def test_hybrid_launch_plan(r_c3):
             assert torch.equal(res[mode][k], res[0][k]), (mode, k)
     print("kernel ms by plan (packets, split, hybrid, auto):", [round(ms[m], 2) for m in (0, 1, 2, -1)])
     assert ms[-1] <= 1.05 * min(ms[0], ms[1], ms[2])
+
+
+@pytest.mark.gpu
+def test_integration_md_ctypes_stub_runs(r_c3):
+    """The ctypes stub printed in INTEGRATION.md section 2 is executed as written (library path substituted, a stand-in
+    object with the reference NeRFModel's attribute names) and must reproduce the wrapper's image bit for bit."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    code = re.search(r"```python\nimport ctypes as C.*?```", text, re.S).group(0)[len("```python\n"):-3]
+    code = code.replace('C.CDLL("libnwe_hip.so")', f'C.CDLL({nwe_amd._lib.LIB_PATH!r})')
+
+    class FakeModel:                                   # attribute names of nerf/models/nerf_model.py:10-43
+        def __init__(self, sd):
+            self._sd = {k: torch.from_numpy(v) for k, v in sd.items()}
+            self._pts_linears = [None] * 8
+            self._W, self._input_ch, self._input_ch_views = 256, 63, 27
+
+        def state_dict(self):
+            return self._sd
+
+    ns = {}
+    exec(code, ns)
+    ns["upload"](0, FakeModel(_sd(1000, 8, 256)))
+    ns["upload"](1, FakeModel(_sd(1001, 8, 256)))
+    fx, fy, cx, cy = O.intrinsics(16, 24)
+    pose = O.camera_pose((0.0, -0.5, -0.77, 0.0, -90.0, 0.0), (0, 0, 0, -30.0, 0.0, 0.0))[0].numpy()
+    img = ns["render"](pose, 16, 24, fx, fy, cx, cy)
+    torch.cuda.synchronize()
+    ref = r_c3.render(pose, 16, 24, fx=fx, fy=fy, cx=cx, cy=cy, near=0.1, far=10.0, outputs=("rgb",))["rgb"].reshape(16, 24, 3)
+    assert torch.equal(img, ref)
+    ns["lib"].nwe_destroy(ns["ctx"])
