@@ -228,7 +228,7 @@ int check_ready(nwe_ctx* ctx, const nwe_outputs* out, int precision) {
     if (precision != NWE_PREC_F32) {
         if (!ctx->net[0].mfma_ok || (ctx->ni > 0 && !ctx->net[1].mfma_ok))
             return fail(ctx, NWE_ERR_UNSUPPORTED,
-                        "no MFMA kernel for this network shape (have 8x256 skip 4 and 4x128, 63/27 inputs); use NWE_PREC_F32");
+                        "no MFMA kernel for this network shape (have 8x256 and 8x128 with the skip after layer 4, 4x256 and 4x128 without, 63/27 inputs); use NWE_PREC_F32");
         if (ctx->ns > mfma_max_samples())
             return fail(ctx, NWE_ERR_UNSUPPORTED, "the MFMA kernel supports n_samples <= 64; use NWE_PREC_F32");
     }

@@ -928,7 +928,8 @@ __global__ void __launch_bounds__(256) render_mfma_kernel(RenderArgs a, NetMfma 
 
 bool mfma_supported(int D, int W, int in_xyz, int in_dir, int skip) {
     if (in_xyz != 63 || in_dir != 27) return false;
-    return (D == 8 && W == 256 && skip == 4) || (D == 4 && W == 128 && skip == -1);
+    return (D == 8 && W == 256 && skip == 4) || (D == 4 && W == 128 && skip == -1) || (D == 8 && W == 128 && skip == 4) ||
+           (D == 4 && W == 256 && skip == -1);
 }
 
 int mfma_max_samples() { return kMfmaMaxSamples; }
@@ -982,6 +983,8 @@ bool launch_render_mfma(const RenderArgs& a, const NetMfma& nc, const NetMfma& n
     if (a.n_samples > kMfmaMaxSamples) return false;
     if (nc.D == 8 && nc.W == 256 && nc.skip == 4) launch_t<256, 8, 4>(a, nc, nf, three_pass, decomposition, stream);
     else if (nc.D == 4 && nc.W == 128 && nc.skip == -1) launch_t<128, 4, -1>(a, nc, nf, three_pass, decomposition, stream);
+    else if (nc.D == 8 && nc.W == 128 && nc.skip == 4) launch_t<128, 8, 4>(a, nc, nf, three_pass, decomposition, stream);
+    else if (nc.D == 4 && nc.W == 256 && nc.skip == -1) launch_t<256, 4, -1>(a, nc, nf, three_pass, decomposition, stream);
     else return false;
     return true;
 }

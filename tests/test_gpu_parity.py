@@ -667,3 +667,30 @@ def test_integration_md_ctypes_stub_runs(r_c3):
     ref = r_c3.render(pose, 16, 24, fx=fx, fy=fy, cx=cx, cy=cy, near=0.1, far=10.0, outputs=("rgb",))["rgb"].reshape(16, 24, 3)
     assert torch.equal(img, ref)
     ns["lib"].nwe_destroy(ns["ctx"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("D,Wn", [(8, 128), (4, 256)])
+def test_further_mfma_shapes(D, Wn):
+    """8x128 (skip after layer 4) and 4x256 (no skip layer, as NeRFModel builds it for D <= 5): MFMA instantiations against
+    the fp32 kernel and the live oracle on the same rays, both decompositions."""
+    sd_c = nwe_amd.synthetic.thin_fog(_sd(1000, D, Wn))
+    sd_f = _sd(1001, D, Wn)
+    r = nwe_amd.Renderer(0)
+    r.set_network(0, sd_c)
+    r.set_network(1, sd_f)
+    r.set_sampling(64, 128)
+    fx, fy, cx, cy = O.intrinsics(20, 24)
+    pose = O.camera_pose((0.0, -0.5, -0.77, 0.0, -90.0, 0.0), (0, 0, 0, -30.0, 0.0, 0.0))
+    rays = O.create_rays(pose, 20, 24, fx, fy, cx, cy, 0.1, 10.0)[0]
+    ref = O.render_rays(rays, _t(sd_c), _t(sd_f), O.RenderConfig())
+    ok = ref["raw_fine"][:, -1, 3].abs().numpy() > 1e-5
+    f32 = r.render_rays(rays.cuda(), precision="f32", outputs=("rgb", "depth"))
+    for mode in (0, 1):
+        r.debug_set_decomposition(mode)
+        got = r.render_rays(rays.cuda(), precision="f16x3", outputs=("rgb", "depth", "raw_coarse"))
+        assert np.abs(got["rgb"].cpu().numpy() - ref["rgb_fine"].numpy())[ok].max() <= RGB_TOL
+        assert np.abs(got["depth"].cpu().numpy() - ref["depth_fine"].numpy())[ok].max() / FAR <= 1e-4
+        assert np.abs(got["raw_coarse"].cpu().numpy() - ref["raw_coarse"].numpy()).max() <= 2e-5
+        assert (got["rgb"] - f32["rgb"]).abs().cpu().numpy()[ok].max() <= RGB_TOL
+    r.close()
