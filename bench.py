@@ -74,6 +74,8 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--precision", default="f16x3", choices=["f16x3", "f16x1", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--unfolded", action="store_true",
+                    help="comparison only: evaluate _feature_linear as its own layer instead of folding it into the view layer at pack time")
     args = ap.parse_args()
 
     import torch.distributed as dist
@@ -95,6 +97,8 @@ def main() -> None:
     sd_f = nwe_amd.synthetic.make_state_dict(1001, 8, 256)
     h = nwe_amd.NeRFReplicaInferenceHandler("office_tokyo", "synthetic", device=local_rank, precision=args.precision)
     h.set_sampling(NS, NI)
+    if args.unfolded:
+        h.debug_set_fold(False)
     h.initialize_models(state_dicts=(sd_c, sd_f))
     tsr = TileShardedRenderer(lambda poses, hh, ww, rows: h.render_batch(poses, hh, ww, rows=rows), rank, world)
 

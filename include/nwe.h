@@ -50,6 +50,8 @@ enum {
  * When n_importance == 0 the "fine" slots receive the coarse results (the reference raises
  * UnboundLocalError there, :263). */
 typedef struct nwe_outputs {
+    uint64_t struct_bytes; /* = sizeof(nwe_outputs): a caller built against another version of this header (fields were
+                              added since) is refused with NWE_ERR_INVALID instead of having pointers misread */
     float *rgb;          /* [R,3]   rgb_fine    */
     float *depth;        /* [R]     depth_fine  */
     float *acc;          /* [R]     acc_fine    */
@@ -62,10 +64,19 @@ typedef struct nwe_outputs {
     float *raw_coarse;   /* [R,n_samples,4]  network output, [rgb_raw(3), sigma_raw] */
     float *raw_fine;     /* [R,S,4]             */
     float *z_fine;       /* [R,S]  sorted sample depths of the fine pass (handler.py:243) */
-    float *sample_cond;  /* [R]    smallest cdf step (`denom`, nerf/rays/rays.py:113) an importance sample of the ray was
-                                   interpolated in (1.0 if none below 1): the sample depth moves by bin_width/denom per
-                                   unit change of the coarse cdf, so a small value marks a ray whose fine samples are an
-                                   ill-conditioned function of the coarse weights IN THE REFERENCE ALGORITHM ITSELF */
+    float *weights_coarse; /* [R,n_samples]  alpha * transmittance of the coarse pass: the 4th return value of raw2outputs
+                                   (nerf/models/model_utils.py:80), whose [..., 1:-1] slice is what sample_pdf takes
+                                   (handler.py:237) */
+    /* Conditioning diagnostics of the importance sampling (nerf/rays/rays.py:103-119), one value per ray, taken over
+     * the importance samples that are interpolated between two different cdf entries (the clamped end case
+     * below == above, :104-105, has a structural denom of 0 and a zero-width bin and is left out): */
+    float *sample_cond;  /* [R]    smallest cdf step `denom` (:113) BEFORE the `denom < 1e-5 -> 1` replacement (:114); a value
+                                   below 1e-5 says that a sample of this ray went through the replacement (1.0 if none) */
+    float *sample_amp;   /* [R]    largest bin_width / denom (denom after the replacement): a sample depth moves by this
+                                   much per unit change of the coarse cdf, i.e. the first-order amplification of a
+                                   rounding difference in the coarse weights IN THE REFERENCE ALGORITHM ITSELF */
+    float *sample_switch;/* [R]    smallest |denom - 1e-5| before the replacement: the distance of the ray's samples
+                                   from the discontinuity of :114 */
     uint32_t *flags;     /* [1]    NWE_FLAG_* bits, OR-ed (caller zeroes it) */
 } nwe_outputs;
 
@@ -100,7 +111,10 @@ int nwe_set_sampling(nwe_ctx *ctx, const float *t_vals, const float *one_minus_t
 /* Render rays [row_begin,row_end) x [0,W) of n_poses pinhole views.  c2w: HOST, n_poses*16 floats,
  * row-major 4x4 camera-to-world.  Output ray index = (p*(row_end-row_begin) + (h-row_begin))*W + w.
  * Ray generation follows nerf/rays/rays.py:6-71; the render loop nerf_replica_inference_handler.py:203-277.
- * Asynchronous on `stream` (a hipStream_t, NULL = default stream).
+ * Asynchronous on `stream` (a hipStream_t, NULL = default stream) when c2w is pageable host memory (the poses are
+ * staged before the call returns); a pinned c2w must stay valid until the stream has passed the call.  A context may
+ * have launches in flight on several streams (each launch owns its pose table); it is still not thread-safe, and with
+ * more than four launches queued the call blocks until the oldest has finished.
  * Replaces: create_rays + rays.cuda() + _render_rays of render_coordinates (handler.py:172-177). */
 int nwe_render(nwe_ctx *ctx, const float *c2w, int n_poses, int H, int W, float fx, float fy, float cx, float cy,
                float near, float far, int row_begin, int row_end, int precision, const nwe_outputs *out,
@@ -144,6 +158,23 @@ float nwe_packed_scale(const nwe_ctx *ctx, int which);
  * sorted per ray) instead of its own importance sampling; cleared after that call.  Lets a test feed the
  * reference's own depths and compare the fine pass alone. */
 int nwe_debug_set_fine_depths(nwe_ctx *ctx, const float *z_dev);
+
+/* Test hooks in the same style (the NEXT nwe_render_rays call, cleared after it); both kernels honour them:
+ *   nwe_debug_set_raw             network outputs from the caller instead of evaluating the MLP: DEVICE raw_coarse
+ *                                 [n_rays, n_samples, 4] and / or raw_fine [n_rays, S, 4] (either may be NULL), so that
+ *                                 compositing (nerf/models/model_utils.py:49-100) is checked on the reference's own
+ *                                 edge vectors (sigma <= 0 everywhere, saturated alpha, sigma_last = +-1e-11);
+ *   nwe_debug_set_coarse_weights  coarse weights [n_rays, n_samples] from the caller instead of running the coarse pass
+ *                                 (its outputs are then not written), so that the inverse-CDF sampling
+ *                                 (nerf/rays/rays.py:74-121) is checked on given weights. */
+int nwe_debug_set_raw(nwe_ctx *ctx, const float *raw_coarse_dev, const float *raw_fine_dev);
+int nwe_debug_set_coarse_weights(nwe_ctx *ctx, const float *weights_dev);
+
+/* Test hook: networks uploaded AFTER this call are packed for the MFMA kernel with (1, the default) or without (0)
+ * _feature_linear multiplied into _views_linears (nerf/models/nerf_model.py:64-70: the feature layer has no activation,
+ * so W_v [W_f h + b_f; gamma(d)] + b_v = (W_v[:, :W] W_f) h + ...; fp64 product on the host).  0 evaluates the feature
+ * layer as the reference formulates it (8x256 and 4x128 only); kept for one-to-one comparison. */
+int nwe_debug_set_fold(nwe_ctx *ctx, int on);
 
 /* rendering.white_background of the reference's YAML (nerf/models/model_utils.py:97-98): when on, every rgb output
  * (coarse and fine) is rgb + (1 - acc).  Off by default, as in all four office configs. */

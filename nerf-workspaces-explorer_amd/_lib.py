@@ -14,17 +14,20 @@ PREC_F16X3, PREC_F16X1, PREC_F32 = 0, 1, 2
 PRECISIONS = {"f16x3": PREC_F16X3, "f16x1": PREC_F16X1, "f32": PREC_F32}
 
 OUTPUT_FIELDS = ("rgb", "depth", "acc", "disp", "z_std", "rgb_coarse", "depth_coarse", "acc_coarse", "disp_coarse",
-                 "raw_coarse", "raw_fine", "z_fine", "sample_cond", "flags")
+                 "raw_coarse", "raw_fine", "z_fine", "weights_coarse", "sample_cond", "sample_amp", "sample_switch", "flags")
 
 # every symbol include/nwe.h declares (tests/test_abi.py checks the library exports all of them)
 SYMBOLS = ("nwe_create", "nwe_destroy", "nwe_last_error", "nwe_set_network", "nwe_set_sampling", "nwe_render",
            "nwe_create_rays", "nwe_render_rays", "nwe_to8b", "nwe_flops_per_eval", "nwe_last_kernel_ms", "nwe_packed_bytes",
            "nwe_packed_copy", "nwe_packed_bias_count", "nwe_packed_bias_copy", "nwe_packed_scale",
-           "nwe_debug_set_fine_depths", "nwe_set_train_tables", "nwe_set_white_background", "nwe_debug_set_decomposition", "nwe_debug_set_stamps", "nwe_selftest")
+           "nwe_debug_set_fine_depths", "nwe_debug_set_raw", "nwe_debug_set_coarse_weights", "nwe_debug_set_fold", "nwe_set_train_tables", "nwe_set_white_background", "nwe_debug_set_decomposition", "nwe_debug_set_stamps", "nwe_selftest")
 
 
 class Outputs(C.Structure):
-    _fields_ = [(name, C.c_void_p) for name in OUTPUT_FIELDS]
+    _fields_ = [("struct_bytes", C.c_uint64)] + [(name, C.c_void_p) for name in OUTPUT_FIELDS]
+
+    def __init__(self, **kw):
+        super().__init__(struct_bytes=C.sizeof(Outputs), **kw)
 
 
 _lib = None
@@ -61,6 +64,9 @@ def load() -> C.CDLL:
         "nwe_packed_bias_copy": (I, [P, I, P, I64]),
         "nwe_packed_scale": (F, [P, I]),
         "nwe_debug_set_fine_depths": (I, [P, P]),
+        "nwe_debug_set_raw": (I, [P, P, P]),
+        "nwe_debug_set_coarse_weights": (I, [P, P]),
+        "nwe_debug_set_fold": (I, [P, I]),
         "nwe_set_train_tables": (I, [P, P, P, P, P]),
         "nwe_set_white_background": (I, [P, I]),
         "nwe_debug_set_decomposition": (I, [P, I]),

@@ -20,6 +20,7 @@ struct NetState {
     NetF32 f32 = {};
     float* d_blob = nullptr;
     bool mfma_ok = false;
+    bool folded = false;           // MFMA stream: _feature_linear multiplied into the view layer
     std::vector<uint8_t> stream;   // MFMA kernel: 1-KiB tiles in consumption order
     std::vector<float> bias_tab;   // MFMA kernel: 32 floats per chunk
     float w_scale = 1.f;           // power of two the packed weights are multiplied by
@@ -38,11 +39,21 @@ struct nwe_ctx {
     NetState net[2];
     float *d_t = nullptr, *d_omt = nullptr, *d_u = nullptr;
     int ns = 0, ni = 0;
-    float* d_poses = nullptr;
-    int poses_cap = 0;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    bool timed = false;
+    // One slot per launch in flight: the pose table a kernel reads and the events around it.  A slot is reused only
+    // after its own launch has finished (its `done` event), so renders of one context queued on different streams never
+    // share a pose buffer.
+    struct Slot {
+        float* d_poses = nullptr;
+        int poses_cap = 0;
+        hipEvent_t ev0 = nullptr, ev1 = nullptr;
+        bool used = false;
+    };
+    static constexpr int kSlots = 4;
+    Slot slots[kSlots];
+    int next_slot = 0, last_slot = -1;
     const float* dbg_z_fine = nullptr;
+    const float *dbg_raw_c = nullptr, *dbg_raw_f = nullptr, *dbg_w = nullptr;   // nwe_debug_set_raw / _coarse_weights, one call
+    int fold = 1;             // nwe_debug_set_fold: read by nwe_set_network
     int white_bkgd = 0;
     int decomposition = -1;   // nwe_debug_set_decomposition
     unsigned long long* stamps = nullptr;   // nwe_debug_set_stamps
@@ -101,7 +112,10 @@ struct RowMap {   // which weight row feeds tile row i (or -1)
     }
 };
 
-void put_tile_pair(std::vector<uint8_t>& out, const float* w, int ld, const RowMap& rows, int rt, const Segment& sg, int s, float scale) {
+// T = float (a layer as the caller handed it over) or double (a product of two layers, see pack_mfma): the value times
+// the power-of-two scale is exact in T, hi = fp16(v), lo = fp16(v - hi) with v - hi exact in T.
+template <class T>
+void put_tile_pair(std::vector<uint8_t>& out, const T* w, int ld, const RowMap& rows, int rt, const Segment& sg, int s, float scale) {
     const size_t base = out.size();
     out.resize(base + 2 * kTileBytes, 0);
     _Float16* hi = reinterpret_cast<_Float16*>(out.data() + base);
@@ -111,38 +125,66 @@ void put_tile_pair(std::vector<uint8_t>& out, const float* w, int ld, const RowM
         const int row = rows(rt, i);
         for (int j = 0; j < 8; ++j) {
             int col = sg.kind == 0 ? hidden_col(s, h, j) : gamma_col(sg.kind == 1 ? 5 : 2, s, h, j);
-            float v = 0.f;
-            if (row >= 0 && col >= 0) v = w[(size_t)row * ld + sg.col_off + col] * scale;   // power of two: exact
+            T v = 0;
+            if (row >= 0 && col >= 0) v = w[(size_t)row * ld + sg.col_off + col] * (T)scale;   // power of two: exact
             const _Float16 vh = (_Float16)v;
             hi[lane * 8 + j] = vh;
-            lo[lane * 8 + j] = (_Float16)(v - (float)vh);
+            lo[lane * 8 + j] = (_Float16)(v - (T)vh);
         }
     }
 }
 
-void put_chunk(NetState& n, const float* w, const float* b, int ld, const RowMap& rows, int rt, const std::vector<Segment>& segs) {
-    for (int i = 0; i < 32; ++i) { const int r = rows(rt, i); n.bias_tab.push_back(r >= 0 ? b[r] : 0.f); }
+template <class T>
+void put_chunk(NetState& n, const T* w, const T* b, int ld, const RowMap& rows, int rt, const std::vector<Segment>& segs) {
+    for (int i = 0; i < 32; ++i) { const int r = rows(rt, i); n.bias_tab.push_back(r >= 0 ? (float)b[r] : 0.f); }
     for (const Segment& sg : segs)
         for (int s = 0; s < sg.ksteps; ++s) put_tile_pair(n.stream, w, ld, rows, rt, sg, s, n.w_scale);
 }
 
 // Stream order = the order mlp_eval() consumes chunks in.
+//
+// n.folded: _feature_linear has no activation (nerf/models/nerf_model.py:64) and its output feeds only the view layer
+// (:66-70), so  W_v [W_f h + b_f ; gamma(d)] + b_v = (W_v[:, :W] W_f) h + W_v[:, W:] gamma(d) + (b_v + W_v[:, :W] b_f):
+// the product is formed here in fp64 and split into (hi, lo) directly from the double, the feature layer's chunks
+// disappear from the stream (8 of 78 chunks, 11 % of the MFMAs of an 8x256 evaluation).
 void pack_mfma(NetState& n, const float* const* w, const float* const* b) {
     const int D = n.D, W = n.W, KH = W / 16;
+    const int iv = D, ife = D + 1, ia = D + 2, irgb = D + 3;
     n.stream.clear();
     n.bias_tab.clear();
+    std::vector<double> wv, bv;   // folded view layer [W/2, W + in_dir] and its bias
+    if (n.folded) {
+        const int ldv = W + n.in_dir;
+        wv.assign((size_t)(W / 2) * ldv, 0.0);
+        bv.assign(W / 2, 0.0);
+        for (int r = 0; r < W / 2; ++r) {
+            const float* vr = w[iv] + (size_t)r * ldv;
+            double* o = wv.data() + (size_t)r * ldv;
+            double acc_b = (double)b[iv][r];
+            for (int k = 0; k < W; ++k) {
+                const double vk = (double)vr[k];
+                const float* fr = w[ife] + (size_t)k * W;
+                for (int c = 0; c < W; ++c) o[c] += vk * (double)fr[c];
+                acc_b += vk * (double)b[ife][k];
+            }
+            for (int c = 0; c < n.in_dir; ++c) o[W + c] = (double)vr[W + c];
+            bv[r] = acc_b;
+        }
+    }
     // One power-of-two scale for the whole network: the largest that keeps every scaled weight below 2^14, so that
     // the lo halves (|lo| <= ulp(hi)/2) are fp16-normal for all but vanishing weights.  The kernel multiplies the
     // accumulator by 1/scale before adding the bias; both scalings are exact.
     const int in_dims[4] = {W + n.in_dir, W, W, W / 2}, out_dims[4] = {W / 2, W, 1, 3};
-    float wmax = 0.f;
+    double wmax = 0.0;
     for (int li = 0; li < D + 4; ++li) {
+        if (n.folded && (li == iv || li == ife)) continue;
         const size_t cnt = li < D ? (size_t)W * (li == 0 ? n.in_xyz : (li == n.skip + 1 ? W + n.in_xyz : W))
                                   : (size_t)in_dims[li - D] * out_dims[li - D];
-        for (size_t k = 0; k < cnt; ++k) wmax = std::max(wmax, std::fabs(w[li][k]));
+        for (size_t k = 0; k < cnt; ++k) wmax = std::max(wmax, (double)std::fabs(w[li][k]));
     }
+    for (double v : wv) wmax = std::max(wmax, std::fabs(v));
     int e = 0;
-    if (wmax > 0.f && std::isfinite(wmax)) { e = 14 - (int)std::ceil(std::log2(wmax)); e = std::min(std::max(e, -14), 30); }
+    if (wmax > 0.0 && std::isfinite(wmax)) { e = 14 - (int)std::ceil(std::log2(wmax)); e = std::min(std::max(e, -14), 30); }
     n.w_scale = std::ldexp(1.f, e);
     auto layer = [&](int li, int n_out, int ld, int n_tiles, int dup4, const std::vector<Segment>& segs) {
         RowMap rows{n_out, dup4};
@@ -153,10 +195,14 @@ void pack_mfma(NetState& n, const float* const* w, const float* const* b) {
         if (i == n.skip + 1) layer(i, W, W + n.in_xyz, W / 32, 0, {{1, 4, 0}, {0, KH, n.in_xyz}});   // cat([pts, h]), nerf_model.py:59
         else layer(i, W, W, W / 32, 0, {{0, KH, 0}});
     }
-    const int iv = D, ife = D + 1, ia = D + 2, irgb = D + 3;
-    layer(ife, W, W, W / 32, 0, {{0, KH, 0}});
+    if (!n.folded) layer(ife, W, W, W / 32, 0, {{0, KH, 0}});
     layer(ia, 1, W, 1, 1, {{0, KH, 0}});
-    layer(iv, W / 2, W + n.in_dir, W / 64, 0, {{0, KH, 0}, {2, 2, W}});                               // cat([feature, views]), :66
+    if (n.folded) {
+        RowMap rows{W / 2, 0};
+        for (int rt = 0; rt < W / 64; ++rt) put_chunk(n, wv.data(), bv.data(), W + n.in_dir, rows, rt, {{0, KH, 0}, {2, 2, W}});
+    } else {
+        layer(iv, W / 2, W + n.in_dir, W / 64, 0, {{0, KH, 0}, {2, 2, W}});                           // cat([feature, views]), :66
+    }
     layer(irgb, 3, W / 2, 1, 1, {{0, KH / 2, 0}});
 }
 
@@ -207,18 +253,38 @@ __global__ void create_rays_kernel(RenderArgs a, float* __restrict__ out) {
     o[6] = r.near; o[7] = r.far; o[8] = r.vx; o[9] = r.vy; o[10] = r.vz;
 }
 
-int upload_poses(nwe_ctx* c, const float* c2w, int n_poses, hipStream_t stream) {
-    if (n_poses > c->poses_cap) {
-        if (c->d_poses) (void)hipFree(c->d_poses);
-        c->poses_cap = std::max(n_poses, 64);
-        HIPCHK(c, hipMalloc(&c->d_poses, (size_t)c->poses_cap * 16 * sizeof(float)));
+// The slot of the next launch: waits for the launch that used it kSlots launches ago (normally long finished).
+int acquire_slot(nwe_ctx* c, nwe_ctx::Slot** out) {
+    nwe_ctx::Slot& s = c->slots[c->next_slot];
+    if (!s.ev0) {
+        HIPCHK(c, hipEventCreate(&s.ev0));
+        HIPCHK(c, hipEventCreate(&s.ev1));
     }
-    HIPCHK(c, hipMemcpyAsync(c->d_poses, c2w, (size_t)n_poses * 16 * sizeof(float), hipMemcpyHostToDevice, stream));
+    if (s.used) HIPCHK(c, hipEventSynchronize(s.ev1));
+    c->last_slot = c->next_slot;
+    c->next_slot = (c->next_slot + 1) % nwe_ctx::kSlots;
+    *out = &s;
+    return NWE_OK;
+}
+
+// Poses into the slot's own table.  hipMemcpyAsync from pageable host memory is staged by the runtime before it returns,
+// so the caller's array is free on return; from pinned memory the copy is truly asynchronous and include/nwe.h asks the
+// caller to keep the array alive until the stream has passed it.
+int upload_poses(nwe_ctx* c, nwe_ctx::Slot& s, const float* c2w, int n_poses, hipStream_t stream) {
+    if (n_poses > s.poses_cap) {
+        if (s.d_poses) { (void)hipFree(s.d_poses); s.d_poses = nullptr; s.poses_cap = 0; }   // its last reader finished (acquire_slot)
+        const int cap = std::max(n_poses, 64);
+        HIPCHK(c, hipMalloc(&s.d_poses, (size_t)cap * 16 * sizeof(float)));
+        s.poses_cap = cap;
+    }
+    HIPCHK(c, hipMemcpyAsync(s.d_poses, c2w, (size_t)n_poses * 16 * sizeof(float), hipMemcpyHostToDevice, stream));
     return NWE_OK;
 }
 
 int check_ready(nwe_ctx* ctx, const nwe_outputs* out, int precision) {
     if (!ctx || !out) return fail(ctx, NWE_ERR_INVALID, "null context or outputs");
+    if (out->struct_bytes != sizeof(nwe_outputs))
+        return fail(ctx, NWE_ERR_INVALID, "nwe_outputs.struct_bytes != sizeof(nwe_outputs): the caller was built against another version of include/nwe.h");
     if (ctx->host_only) return fail(ctx, NWE_ERR_STATE, "host-only context cannot render");
     if (ctx->ns <= 0) return fail(ctx, NWE_ERR_STATE, "nwe_set_sampling has not been called");
     if (!ctx->net[0].set) return fail(ctx, NWE_ERR_STATE, "coarse network not set");
@@ -228,21 +294,21 @@ int check_ready(nwe_ctx* ctx, const nwe_outputs* out, int precision) {
     if (precision != NWE_PREC_F32) {
         if (!ctx->net[0].mfma_ok || (ctx->ni > 0 && !ctx->net[1].mfma_ok))
             return fail(ctx, NWE_ERR_UNSUPPORTED,
-                        "no MFMA kernel for this network shape (have 8x256 and 8x128 with the skip after layer 4, 4x256 and 4x128 without, 63/27 inputs); use NWE_PREC_F32");
+                        "no MFMA kernel for this network shape (have widths 128 and 256 with depth 6 or 8 and the skip after layer 4, or depth 4 without, 63/27 inputs); use NWE_PREC_F32");
         if (ctx->ns > mfma_max_samples())
             return fail(ctx, NWE_ERR_UNSUPPORTED, "the MFMA kernel supports n_samples <= 64; use NWE_PREC_F32");
     }
     return NWE_OK;
 }
 
-int launch(nwe_ctx* ctx, RenderArgs& a, int precision, void* stream_) {
+int launch(nwe_ctx* ctx, nwe_ctx::Slot& slot, RenderArgs& a, int precision, void* stream_) {
     a.white_bkgd = ctx->white_bkgd;
     hipStream_t stream = (hipStream_t)stream_;
     a.t_vals = ctx->d_t; a.omt_vals = ctx->d_omt; a.u_vals = ctx->d_u;
     a.n_samples = ctx->ns; a.n_importance = ctx->ni;
     a.stamps = ctx->stamps;   // only read by -DNWE_STAMPS builds of the kernel (nwe_debug_set_stamps)
     if (a.n_rays <= 0) return NWE_OK;
-    HIPCHK(ctx, hipEventRecord(ctx->ev0, stream));
+    HIPCHK(ctx, hipEventRecord(slot.ev0, stream));
     if (precision == NWE_PREC_F32) {
         launch_render_f32(a, ctx->net[0].f32, ctx->net[ctx->ni > 0 ? 1 : 0].f32, stream);
     } else {
@@ -250,8 +316,8 @@ int launch(nwe_ctx* ctx, RenderArgs& a, int precision, void* stream_) {
             return fail(ctx, NWE_ERR_UNSUPPORTED, "coarse and fine networks must have the same shape for the MFMA kernel");
     }
     HIPCHK(ctx, hipGetLastError());
-    HIPCHK(ctx, hipEventRecord(ctx->ev1, stream));
-    ctx->timed = true;
+    HIPCHK(ctx, hipEventRecord(slot.ev1, stream));
+    slot.used = true;
     return NWE_OK;
 }
 
@@ -266,8 +332,6 @@ int nwe_create(nwe_ctx** out, int device) {
     c->host_only = device < 0;
     if (!c->host_only) {
         hipError_t e = hipSetDevice(device);
-        if (e == hipSuccess) e = hipEventCreate(&c->ev0);
-        if (e == hipSuccess) e = hipEventCreate(&c->ev1);
         if (e != hipSuccess) {
             g_create_error = std::string("nwe_create: ") + hipGetErrorString(e);
             delete c;
@@ -284,9 +348,12 @@ void nwe_destroy(nwe_ctx* c) {
         (void)hipSetDevice(c->device);
         for (NetState& n : c->net) { if (n.d_blob) (void)hipFree(n.d_blob); if (n.d_stream) (void)hipFree(n.d_stream); if (n.d_bias) (void)hipFree(n.d_bias); }
         if (c->d_t) (void)hipFree(c->d_t);
-        if (c->d_poses) (void)hipFree(c->d_poses);
-        if (c->ev0) (void)hipEventDestroy(c->ev0);
-        if (c->ev1) (void)hipEventDestroy(c->ev1);
+        for (nwe_ctx::Slot& sl : c->slots) {
+            if (sl.used) (void)hipEventSynchronize(sl.ev1);
+            if (sl.d_poses) (void)hipFree(sl.d_poses);
+            if (sl.ev0) (void)hipEventDestroy(sl.ev0);
+            if (sl.ev1) (void)hipEventDestroy(sl.ev1);
+        }
     }
     delete c;
 }
@@ -305,13 +372,16 @@ int nwe_set_network(nwe_ctx* c, int which, int depth, int width, int in_xyz, int
     for (int i = 0; i < depth + 4; ++i)
         if (!w[i] || !b[i]) return fail(c, NWE_ERR_INVALID, "null weight or bias pointer");
     NetState& n = c->net[which];
+    n.set = false;   // stays false if anything below fails
     n.D = depth; n.W = width; n.in_xyz = in_xyz; n.in_dir = in_dir; n.skip = skip_layer;
     n.flops = algo_flops(n);
     pack_f32(n, w, b);
-    n.mfma_ok = mfma_supported(depth, width, in_xyz, in_dir, skip_layer);
+    n.folded = c->fold != 0;
+    n.mfma_ok = mfma_supported(depth, width, in_xyz, in_dir, skip_layer, n.folded);
     if (n.mfma_ok) pack_mfma(n, w, b); else { n.stream.clear(); n.bias_tab.clear(); }
     n.mf = {};
-    n.mf.D = depth; n.mf.W = width; n.mf.skip = skip_layer; n.mf.n_tiles = (int)(n.stream.size() / kTileBytes);
+    n.mf.D = depth; n.mf.W = width; n.mf.skip = skip_layer; n.mf.folded = n.folded ? 1 : 0;
+    n.mf.n_tiles = (int)(n.stream.size() / kTileBytes);
     n.mf.n_chunks = (int)(n.bias_tab.size() / 32);
     n.mf.inv_scale = 1.f / n.w_scale;
     if (!c->host_only) {
@@ -363,15 +433,19 @@ int nwe_render(nwe_ctx* c, const float* c2w, int n_poses, int H, int W, float fx
         return fail(c, NWE_ERR_INVALID, "bad pose / image / row range");
     if (!(fx != 0.f) || !(fy != 0.f)) return fail(c, NWE_ERR_INVALID, "fx and fy must be non-zero");
     HIPCHK(c, hipSetDevice(c->device));
-    rc = upload_poses(c, c2w, n_poses, (hipStream_t)stream);
+    nwe_ctx::Slot* slot = nullptr;
+    rc = acquire_slot(c, &slot);
+    if (rc) return rc;
+    rc = upload_poses(c, *slot, c2w, n_poses, (hipStream_t)stream);
     if (rc) return rc;
     RenderArgs a = {};
-    a.rays = nullptr; a.poses = c->d_poses;
+    a.rays = nullptr; a.poses = slot->d_poses;
     a.H = H; a.W = W; a.row_begin = row_begin; a.rows = row_end - row_begin;
     a.n_rays = (int64_t)n_poses * a.rows * W;
+    if (a.n_rays > INT32_MAX) return fail(c, NWE_ERR_INVALID, "more than 2^31 - 1 rays in one call");
     a.fx = fx; a.fy = fy; a.cx = cx; a.cy = cy; a.near = near; a.far = far;
     a.out = *out;
-    return launch(c, a, precision, stream);
+    return launch(c, *slot, a, precision, stream);
 }
 
 int nwe_create_rays(nwe_ctx* c, const float* c2w, int n_poses, int H, int W, float fx, float fy, float cx, float cy, float near,
@@ -380,33 +454,46 @@ int nwe_create_rays(nwe_ctx* c, const float* c2w, int n_poses, int H, int W, flo
     if (!c2w || !rays_out_dev || n_poses < 1 || H < 1 || W < 1 || row_begin < 0 || row_end > H || row_begin > row_end)
         return fail(c, NWE_ERR_INVALID, "bad pose / image / row range");
     HIPCHK(c, hipSetDevice(c->device));
-    int rc = upload_poses(c, c2w, n_poses, (hipStream_t)stream);
+    nwe_ctx::Slot* slot = nullptr;
+    int rc = acquire_slot(c, &slot);
+    if (rc) return rc;
+    rc = upload_poses(c, *slot, c2w, n_poses, (hipStream_t)stream);
     if (rc) return rc;
     RenderArgs a = {};
-    a.poses = c->d_poses;
+    a.poses = slot->d_poses;
     a.H = H; a.W = W; a.row_begin = row_begin; a.rows = row_end - row_begin;
     a.n_rays = (int64_t)n_poses * a.rows * W;
     a.fx = fx; a.fy = fy; a.cx = cx; a.cy = cy; a.near = near; a.far = far;
     if (a.n_rays == 0) return NWE_OK;
+    HIPCHK(c, hipEventRecord(slot->ev0, (hipStream_t)stream));
     hipLaunchKernelGGL(create_rays_kernel, dim3((unsigned)((a.n_rays + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, rays_out_dev);
     HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipEventRecord(slot->ev1, (hipStream_t)stream));
+    slot->used = true;
     return NWE_OK;
 }
 
 int nwe_render_rays(nwe_ctx* c, const float* rays_dev, int64_t n_rays, int precision, const nwe_outputs* out, void* stream) {
     int rc = check_ready(c, out, precision);
     if (rc) return rc;
-    if (n_rays < 0 || (!rays_dev && n_rays > 0)) return fail(c, NWE_ERR_INVALID, "bad rays");
-    if (n_rays == 0) { c->dbg_z_fine = nullptr; c->trn_t = c->trn_nc = c->trn_nf = c->trn_u = nullptr; return NWE_OK; }
+    if (n_rays < 0 || n_rays > INT32_MAX || (!rays_dev && n_rays > 0)) return fail(c, NWE_ERR_INVALID, "bad rays (null, or more than 2^31 - 1)");
+    if (n_rays == 0) {
+        c->dbg_z_fine = c->dbg_raw_c = c->dbg_raw_f = c->dbg_w = nullptr;
+        c->trn_t = c->trn_nc = c->trn_nf = c->trn_u = nullptr;
+        return NWE_OK;
+    }
     HIPCHK(c, hipSetDevice(c->device));
+    nwe_ctx::Slot* slot = nullptr;
+    rc = acquire_slot(c, &slot);
+    if (rc) return rc;
     RenderArgs a = {};
     a.rays = rays_dev; a.n_rays = n_rays; a.W = 1; a.rows = 1;
-    a.z_fine_in = c->dbg_z_fine;
-    c->dbg_z_fine = nullptr;
+    a.z_fine_in = c->dbg_z_fine; a.raw_in_c = c->dbg_raw_c; a.raw_in_f = c->dbg_raw_f; a.w_in = c->dbg_w;
+    c->dbg_z_fine = c->dbg_raw_c = c->dbg_raw_f = c->dbg_w = nullptr;
     a.t_rand = c->trn_t; a.noise_c = c->trn_nc; a.noise_f = c->trn_nf; a.u_rand = c->trn_u;
     c->trn_t = c->trn_nc = c->trn_nf = c->trn_u = nullptr;
     a.out = *out;
-    return launch(c, a, precision, stream);
+    return launch(c, *slot, a, precision, stream);
 }
 
 int nwe_to8b(nwe_ctx* c, const float* rgb_dev, uint8_t* out_dev, int64_t n, void* stream) {
@@ -424,10 +511,11 @@ int64_t nwe_flops_per_eval(const nwe_ctx* c, int which) {
 }
 
 float nwe_last_kernel_ms(nwe_ctx* c) {
-    if (!c || c->host_only || !c->timed) return -1.f;
-    if (hipEventSynchronize(c->ev1) != hipSuccess) return -1.f;
+    if (!c || c->host_only || c->last_slot < 0 || !c->slots[c->last_slot].used) return -1.f;
+    const nwe_ctx::Slot& s = c->slots[c->last_slot];
+    if (hipEventSynchronize(s.ev1) != hipSuccess) return -1.f;
     float ms = -1.f;
-    if (hipEventElapsedTime(&ms, c->ev0, c->ev1) != hipSuccess) return -1.f;
+    if (hipEventElapsedTime(&ms, s.ev0, s.ev1) != hipSuccess) return -1.f;
     return ms;
 }
 
@@ -463,6 +551,24 @@ float nwe_packed_scale(const nwe_ctx* c, int which) {
 int nwe_debug_set_fine_depths(nwe_ctx* c, const float* z_dev) {
     if (!c) return NWE_ERR_INVALID;
     c->dbg_z_fine = z_dev;
+    return NWE_OK;
+}
+
+int nwe_debug_set_raw(nwe_ctx* c, const float* raw_coarse_dev, const float* raw_fine_dev) {
+    if (!c) return NWE_ERR_INVALID;
+    c->dbg_raw_c = raw_coarse_dev; c->dbg_raw_f = raw_fine_dev;
+    return NWE_OK;
+}
+
+int nwe_debug_set_coarse_weights(nwe_ctx* c, const float* weights_dev) {
+    if (!c) return NWE_ERR_INVALID;
+    c->dbg_w = weights_dev;
+    return NWE_OK;
+}
+
+int nwe_debug_set_fold(nwe_ctx* c, int on) {
+    if (!c) return NWE_ERR_INVALID;
+    c->fold = on ? 1 : 0;
     return NWE_OK;
 }
 

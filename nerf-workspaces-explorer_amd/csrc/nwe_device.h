@@ -32,6 +32,9 @@ struct RenderArgs {
     const float* omt_vals;
     const float* u_vals;
     const float* z_fine_in;  // test hook: fine depths [n_rays, ns+ni] instead of importance sampling
+    const float* raw_in_c;   // test hook: network outputs [n_rays, ns, 4] of the coarse pass instead of evaluating the MLP
+    const float* raw_in_f;   // test hook: ... [n_rays, ns+ni, 4] of the fine pass
+    const float* w_in;       // test hook: coarse weights [n_rays, ns] instead of the coarse pass (its outputs are not written)
     // training-mode forward (nerf/training/nerf_replica_training_handler.py:553-580): random numbers drawn by the host
     // where the reference calls torch.rand / torch.randn, one row per ray of this call; each may be null (= inference)
     const float* t_rand;     // [n_rays, ns]      stratified jitter in [0,1)                 (:560-562)
@@ -95,7 +98,8 @@ __device__ __forceinline__ float coarse_z(const Ray& r, float t, float omt) {
 // upper = [mids, z[-1]], lower = [z[0], mids], z = lower + (upper - lower) * t_rand.
 struct CoarseDepths {
     const float* t_tab; const float* omt_tab;   // LDS tables t, 1-t
-    const float* jitter;                        // this ray's t_rand row (global) or null
+    const float* jitter;                        // t_rand [n_rays, ns] (global, wave-uniform pointer) or null
+    int row;                                    // this ray's row in the per-ray tables of the call
     int ns;
     __device__ __forceinline__ float base(const Ray& r, int i) const { return coarse_z(r, t_tab[i], omt_tab[i]); }
     __device__ __forceinline__ float z(const Ray& r, int i) const {
@@ -103,7 +107,7 @@ struct CoarseDepths {
         if (!jitter) return zi;
         const float lower = i > 0 ? __fmul_rn(.5f, __fadd_rn(zi, base(r, i - 1))) : zi;
         const float upper = i + 1 < ns ? __fmul_rn(.5f, __fadd_rn(base(r, i + 1), zi)) : zi;
-        return __fadd_rn(lower, __fmul_rn(__fsub_rn(upper, lower), jitter[i]));
+        return __fadd_rn(lower, __fmul_rn(__fsub_rn(upper, lower), jitter[(int64_t)row * ns + i]));
     }
 };
 
@@ -164,61 +168,130 @@ struct Composite {
 // samples are each already sorted, so torch.sort(cat(...)) is a two-way merge of the same values.
 // `wc` points at this ray's coarse weights in LDS, element i at wc[i*stride]; prepare() overwrites
 // elements 0..ns-2 with the cdf (rays.py:87-90).
+// What the importance samples of a ray look like as a whole: z_std (handler.py:267) and the conditioning diagnostics of
+// include/nwe.h.  A pure function of the cdf, computed once per ray by FineSampler::survey() and stored at once, so that
+// none of it is carried through the fine pass.
+struct SampleSurvey {
+    float z_std;
+    float min_denom;   // smallest cdf step BEFORE the < 1e-5 -> 1 replacement (samples between two different cdf entries)
+    float max_amp;     // largest bin width / cdf step used
+    float min_switch;  // smallest |cdf step - 1e-5|
+};
+
 struct FineSampler {
     float* wc; int stride;
     CoarseDepths cd;
     const float* u_tab;      // LDS table of the deterministic u (rays.py:95)
-    const float* u_row;      // this ray's ascending random u (rays.py:98, global) or null
+    const float* u_rand;     // ascending random u [n_rays, ni] (rays.py:98, global, wave-uniform pointer) or null; row = cd.row
     int ns, ni;
     int ci, fj, ptr;
     float cur_f;
-    double s1, s2;   // sum / sum of squares of the importance samples (z_std, handler.py:267)
-    float min_denom; // smallest cdf step a sample was interpolated in (conditioning diagnostic)
 
     __device__ __forceinline__ float zc(const Ray& r, int i) const { return cd.z(r, i); }
     __device__ __forceinline__ float zmid(const Ray& r, int k) const {       // handler.py:236
         return __fmul_rn(.5f, __fadd_rn(zc(r, k + 1), zc(r, k)));
     }
+    // torch.sum(weights, -1) (rays.py:88) in the order torch's CPU kernel adds a contiguous fp32 row on x86
+    // (aten/src/ATen/native/cpu/SumKernel.cpp: vectorized_inner_sum / row_sum; sum_stub has no AVX-512 registration, so the
+    // 8-lane kernel runs on every AVX2-or-later machine): the row is cut into 8-wide vectors; vector 4g+k goes to partial
+    // accumulator k (k < 4, while whole groups of four last), the vectors left over to accumulator 0, then accumulators 1..3
+    // are added to 0; the scalar result starts with the elements behind the last whole vector and then adds the eight
+    // lanes.  The plain left-to-right sum differs from it by up to 21 ulp on the benchmark scene, which the inverse CDF of
+    // a nearly empty bin amplifies into a visible depth shift; with this order the cdf is torch's bit for bit.
+    // Rows shorter than one vector take the scalar kernel (scalar_inner_sum): the same four interleaved accumulators
+    // over single elements.  Element i is weights[i + 1] + 1e-5 (rays.py:87).  n <= 126 keeps the cascade levels of
+    // multi_row_sum out of play.  (tests/test_host_logic.py restates this in numpy and checks it against torch.sum.)
+    __device__ __forceinline__ float torch_sum_order(int n) const {
+        if (n < 8) {
+            float p[4] = {0.f, 0.f, 0.f, 0.f};
+            const int ng4 = n >> 2;
+            for (int g = 0; g < ng4; ++g)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) p[k] = __fadd_rn(p[k], __fadd_rn(wc[(4 * g + k + 1) * stride], 1e-5f));
+            for (int i = 4 * ng4; i < n; ++i) p[0] = __fadd_rn(p[0], __fadd_rn(wc[(i + 1) * stride], 1e-5f));
+            return __fadd_rn(__fadd_rn(__fadd_rn(p[0], p[1]), p[2]), p[3]);
+        }
+        const int nv = n >> 3, ng = nv >> 2;
+        float acc = 0.f;
+        for (int k = 8 * nv; k < n; ++k) acc = __fadd_rn(acc, __fadd_rn(wc[(k + 1) * stride], 1e-5f));
+        for (int l = 0; l < 8; ++l) {
+            float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;
+            for (int g = 0; g < ng; ++g) {
+                const int e = 32 * g + l + 1;
+                p0 = __fadd_rn(p0, __fadd_rn(wc[e * stride], 1e-5f));
+                p1 = __fadd_rn(p1, __fadd_rn(wc[(e + 8) * stride], 1e-5f));
+                p2 = __fadd_rn(p2, __fadd_rn(wc[(e + 16) * stride], 1e-5f));
+                p3 = __fadd_rn(p3, __fadd_rn(wc[(e + 24) * stride], 1e-5f));
+            }
+            for (int i = 4 * ng; i < nv; ++i) p0 = __fadd_rn(p0, __fadd_rn(wc[(8 * i + l + 1) * stride], 1e-5f));
+            p0 = __fadd_rn(__fadd_rn(__fadd_rn(p0, p1), p2), p3);
+            acc = __fadd_rn(acc, p0);
+        }
+        return acc;
+    }
     __device__ __forceinline__ void prepare(const Ray& r) {
         // weights[..., 1:-1] + 1e-5, normalised, cumulative (double accumulator, float per element)
-        float sum = 0.f;
-        for (int i = 1; i < ns - 1; ++i) sum = __fadd_rn(sum, __fadd_rn(wc[i * stride], 1e-5f));
+        const float sum = torch_sum_order(ns - 2);
         double run = 0.0;
         wc[0] = 0.f;                                                         // rays.py:90 leading zero
         for (int i = 1; i < ns - 1; ++i) {                                   // cdf[i] replaces weight i in place
             run += (double)__fdiv_rn(__fadd_rn(wc[i * stride], 1e-5f), sum);
             wc[i * stride] = (float)run;
         }
-        ci = 0; fj = 0; ptr = 0; s1 = 0.0; s2 = 0.0; min_denom = 1.f;
-        cur_f = sample(r, 0);
+        ci = 0; fj = 0; ptr = 0;
+        cur_f = sample(r, 0, ptr, nullptr);
     }
-    // importance sample j (u ascending, so the searchsorted position only moves forward)
-    __device__ __forceinline__ float sample(const Ray& r, int j) {
+    // Importance sample j (u ascending, so the searchsorted position `p` only moves forward); sv != null also records the
+    // sample's conditioning.
+    __device__ __forceinline__ float sample(const Ray& r, int j, int& p, SampleSurvey* sv) const {
         const int ncdf = ns - 1;
-        const float u = u_row ? u_row[j] : u_tab[j];
-        while (ptr < ncdf && wc[ptr * stride] <= u) ++ptr;                   // searchsorted(right=True), :103
-        const int below = max(ptr - 1, 0), above = min(ptr, ncdf - 1);       // :104-105
+        const float u = u_rand ? u_rand[(int64_t)cd.row * ni + j] : u_tab[j];
+        while (p < ncdf && wc[p * stride] <= u) ++p;                         // searchsorted(right=True), :103
+        const int below = max(p - 1, 0), above = min(p, ncdf - 1);           // :104-105
         const float cb = wc[below * stride], ca = wc[above * stride];
         const float bb = zmid(r, below), ba = zmid(r, above);
         float denom = __fsub_rn(ca, cb);                                     // :113
-        if (denom < 1e-5f) denom = 1.f;
-        min_denom = fminf(min_denom, denom);
+        const float raw_denom = denom;
+        if (denom < 1e-5f) denom = 1.f;                                      // :114
+        const float width = __fsub_rn(ba, bb);
+        if (sv) {
+            if (above != below) {
+                sv->min_denom = fminf(sv->min_denom, raw_denom);
+                sv->min_switch = fminf(sv->min_switch, fabsf(raw_denom - 1e-5f));
+                sv->max_amp = fmaxf(sv->max_amp, width / denom);
+            } else if (ncdf >= 2) {
+                // u at or above the last cdf entry (u = 1.0 against a cdf that ends at 1 - 1 ulp, :103-105): the sample sits on
+                // the last bin edge.  Whether it does is itself a rounding matter - with the last entry one ulp higher the
+                // sample is interpolated in the last bin - so that bin's step counts for the amplification.
+                float dl = __fsub_rn(wc[(ncdf - 1) * stride], wc[(ncdf - 2) * stride]);
+                if (dl < 1e-5f) dl = 1.f;
+                sv->max_amp = fmaxf(sv->max_amp, __fsub_rn(zmid(r, ncdf - 1), zmid(r, ncdf - 2)) / dl);
+            }
+        }
         const float t = __fdiv_rn(__fsub_rn(u, cb), denom);                  // :118
-        const float z = __fadd_rn(bb, __fmul_rn(t, __fsub_rn(ba, bb)));      // :119
-        s1 += (double)z; s2 += (double)z * (double)z;
-        return z;
+        return __fadd_rn(bb, __fmul_rn(t, width));                           // :119
+    }
+    // All importance samples of the ray once over (after prepare()): std(z_samples, unbiased=False) (handler.py:267) and
+    // the conditioning diagnostics.
+    __device__ __forceinline__ SampleSurvey survey(const Ray& r) const {
+        SampleSurvey sv = {0.f, 1.f, 0.f, 1.f};
+        double s1 = 0.0, s2 = 0.0;
+        int p = 0;
+        for (int j = 0; j < ni; ++j) {
+            const float z = sample(r, j, p, &sv);
+            s1 += (double)z; s2 += (double)z * (double)z;
+        }
+        const double m = s1 / ni, v = s2 / ni - m * m;
+        sv.z_std = (float)sqrt(v > 0.0 ? v : 0.0);
+        return sv;
     }
     __device__ __forceinline__ float next(const Ray& r) {
         const float a = ci < ns ? zc(r, ci) : INFINITY;
         const float f = fj < ni ? cur_f : INFINITY;
         if (!(fj < ni) || a <= f) { ++ci; return a; }
         ++fj;
-        if (fj < ni) cur_f = sample(r, fj);
+        if (fj < ni) cur_f = sample(r, fj, ptr, nullptr);
         return f;
-    }
-    __device__ __forceinline__ float z_std() const {                         // unbiased=False
-        const double m = s1 / ni, v = s2 / ni - m * m;
-        return (float)sqrt(v > 0.0 ? v : 0.0);
     }
 };
 
@@ -288,6 +361,17 @@ __device__ __forceinline__ uint32_t store_ray(const nwe_outputs& o, int64_t idx,
     const uint32_t f = ((bad(c.r) || bad(c.g) || bad(c.b)) ? NWE_FLAG_RGB : 0) | (bad(c.depth) ? NWE_FLAG_DEPTH : 0) |
                        (bad(c.acc) ? NWE_FLAG_ACC : 0) | (bad(d) ? NWE_FLAG_DISP : 0);
     return fine ? f : (f << 4);   // the coarse flag bits sit 4 above the fine ones
+}
+
+__device__ __forceinline__ bool wants_survey(const nwe_outputs& o) {
+    return o.z_std || o.sample_cond || o.sample_amp || o.sample_switch;
+}
+__device__ __forceinline__ uint32_t store_survey(const nwe_outputs& o, int64_t idx, const SampleSurvey& sv) {
+    if (o.z_std) o.z_std[idx] = sv.z_std;
+    if (o.sample_cond) o.sample_cond[idx] = sv.min_denom;
+    if (o.sample_amp) o.sample_amp[idx] = sv.max_amp;
+    if (o.sample_switch) o.sample_switch[idx] = sv.min_switch;
+    return (o.z_std && bad(sv.z_std)) ? NWE_FLAG_ZSTD : 0;
 }
 
 }  // namespace nwe

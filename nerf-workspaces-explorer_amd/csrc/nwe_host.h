@@ -29,10 +29,11 @@ struct NetMfma {
     int n_tiles, n_chunks;
     float inv_scale;        // weights are stored multiplied by 1/inv_scale (a power of two)
     int D, W, skip;
+    int folded;             // 1: _feature_linear multiplied into the view layer at pack time (the stream has no feature chunks)
 };
 
 // true if a kernel instantiation exists for this shape
-bool mfma_supported(int D, int W, int in_xyz, int in_dir, int skip);
+bool mfma_supported(int D, int W, int in_xyz, int in_dir, int skip, bool folded);
 // returns false if the shape has no instantiation.  decomposition: -1 = pick by frame size, 0 = four ray packets per
 // workgroup, 1 = one packet per workgroup with its samples dealt to the four waves, 2 = full rounds as 0 and the ragged
 // last round as 1 in a second launch (bit-identical results)

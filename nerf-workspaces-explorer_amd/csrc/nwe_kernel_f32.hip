@@ -110,19 +110,28 @@ __global__ void __launch_bounds__(256) render_f32_kernel(RenderArgs a, NetF32 nc
     fs.wc = s_w + tid; fs.stride = kRP; fs.u_tab = s_u; fs.ns = ns; fs.ni = ni;
     fs.cd.t_tab = s_t; fs.cd.omt_tab = s_omt; fs.cd.ns = ns;
     const int64_t rrow = live ? ridx : a.n_rays - 1;
-    fs.cd.jitter = a.t_rand ? a.t_rand + rrow * ns : nullptr;
-    fs.u_row = a.u_rand ? a.u_rand + rrow * ni : nullptr;
+    fs.cd.jitter = a.t_rand; fs.cd.row = (int)rrow;
+    fs.u_rand = a.u_rand;
     uint32_t flags = 0;
 
     for (int pass = 0; pass < (ni > 0 ? 2 : 1); ++pass) {
         const NetF32& net = pass == 0 ? nc : nf;
         const int S = pass == 0 ? ns : ns + ni;
+        const float* raw_in = pass == 0 ? a.raw_in_c : a.raw_in_f;          // test hook: network outputs from the caller
+        if (pass == 0 && a.w_in) {                                          // test hook: coarse weights from the caller
+            if (owner) for (int s = 0; s < ns; ++s) s_w[s * kRP + tid] = a.w_in[rrow * ns + s];
+            continue;
+        }
         float z_cur = 0.f, z_next = 0.f;
         if (owner) {
             comp.reset();
             if (pass == 0) { z_cur = fs.cd.z(ray, 0); }
             else {
                 fs.prepare(ray);
+                if (wants_survey(a.out)) {
+                    const SampleSurvey sv = fs.survey(ray);
+                    if (live) flags |= store_survey(a.out, ridx, sv);
+                }
                 z_cur = a.z_fine_in ? a.z_fine_in[(live ? ridx : a.n_rays - 1) * S] : fs.next(ray);
             }
         }
@@ -136,6 +145,12 @@ __global__ void __launch_bounds__(256) render_f32_kernel(RenderArgs a, NetF32 nc
                 s_pt[0 * kRP + tid] = px; s_pt[1 * kRP + tid] = py; s_pt[2 * kRP + tid] = pz;
             }
             __syncthreads();
+            if (raw_in) {
+                if (owner) {
+                    const float4 v = *reinterpret_cast<const float4*>(raw_in + (rrow * S + s) * 4);
+                    s_raw[0 * kRP + tid] = v.x; s_raw[1 * kRP + tid] = v.y; s_raw[2 * kRP + tid] = v.z; s_raw[3 * kRP + tid] = v.w;
+                }
+            } else {
             encode16(s_gx, s_pt, net.in_xyz, 10.f);   // handler.py:93 scalar_factor = 10
             __syncthreads();
             // trunk: nerf_model.py:53-59
@@ -151,6 +166,7 @@ __global__ void __launch_bounds__(256) render_f32_kernel(RenderArgs a, NetF32 nc
             dense16(net.blob, net.feature, cur, net.W, nullptr, 0, nxt, false);
             dense16(net.blob, net.views, nxt, net.W, s_gd, net.in_dir, cur, true);
             dense16(net.blob, net.rgb, cur, net.W / 2, nullptr, 0, s_raw, false);
+            }
             if (owner) {
                 const float rr = s_raw[0 * kRP + tid], rg = s_raw[1 * kRP + tid], rb = s_raw[2 * kRP + tid],
                             rs = s_raw[3 * kRP + tid];
@@ -158,6 +174,7 @@ __global__ void __launch_bounds__(256) render_f32_kernel(RenderArgs a, NetF32 nc
                 const float w = comp.step(rr, rg, rb, rs, z_cur, z_next, s + 1 == S, ray.dnorm, nz ? nz[rrow * S + s] : 0.f);
                 if (pass == 0) s_w[s * kRP + tid] = w;
                 if (live) {
+                    if (pass == 0 && a.out.weights_coarse) a.out.weights_coarse[ridx * S + s] = w;
                     float* raw = pass == 0 ? a.out.raw_coarse : a.out.raw_fine;
                     if (raw) {
                         float4* dst = reinterpret_cast<float4*>(raw + (ridx * S + s) * 4);
@@ -174,12 +191,6 @@ __global__ void __launch_bounds__(256) render_f32_kernel(RenderArgs a, NetF32 nc
         if (live) {
             flags |= store_ray(a.out, ridx, comp, pass == 1, a.white_bkgd != 0);
             if (ni == 0) flags |= store_ray(a.out, ridx, comp, true, a.white_bkgd != 0);   // coarse-only: fill the "fine" slots too
-            if (pass == 1 && a.out.z_std) {
-                const float zs = fs.z_std();
-                a.out.z_std[ridx] = zs;
-                if (bad(zs)) flags |= NWE_FLAG_ZSTD;
-            }
-            if (pass == 1 && a.out.sample_cond) a.out.sample_cond[ridx] = fs.min_denom;
         }
     }
     if (flags && a.out.flags) atomicOr(a.out.flags, flags);

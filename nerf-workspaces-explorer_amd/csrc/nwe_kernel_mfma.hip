@@ -52,7 +52,11 @@ struct Shape {
     static constexpr int N_V = 2 * (KH + KD) / kWaves;
     static constexpr int N_RGB = 2 * KV / kWaves;
     static constexpr int CHUNK_BYTES = N_S * kWaves * kTileBytes;
-    static constexpr int N_CHUNKS = NT + D * NT + 1 + NTV + 1;   // layer 0, D/2 pairs, alpha, views, rgb
+    static constexpr int N_CHUNKS = NT + D * NT + 1 + NTV + 1;   // layer 0, D-1 trunk layers + feature, alpha, views, rgb (unfolded: the larger count)
+    static constexpr int N_CHUNKS_FOLDED = N_CHUNKS - NT;        // _feature_linear folded into the view layer at pack time
+    // A LONG chunk (>= 16 k-steps, three-pass mode) keeps the (hi, lo) tiles of its last k-step in a rotating tail slot
+    // instead of the chunk buffer, see Walker.
+    static constexpr int LONG_PIECES = 8;
 };
 
 // A 32-row tile whose accumulator is complete but whose epilogue (scale, bias, ReLU, fp16 hi/lo split into the B
@@ -245,12 +249,27 @@ __device__ __forceinline__ void mma3(const h8& a_hi, const h8& a_lo, const h8& x
 //     earlier).  After it (a) chunk T+1 is visible, so the A fragments of tile T+1's first PD k-steps are read
 //     during the last PD k-steps of tile T and the matrix pipe does not drain at the tile boundary, and (b) buffer
 //     T&1 is free, so the DMA of chunk T+2 starts at once: its first PD pieces in tile T, the rest early in T+1.
+//   * On the long tiles the pre-barrier wait leaves the two fragment reads issued one k-step earlier in flight
+//     (lgkmcnt(2): waiting for them too costs an LDS round trip per tile, 5 % of the frame).  Those two reads fetch the
+//     (hi, lo) tiles of the chunk's LAST k-step, and these do not live in the chunk buffer the barrier releases but in
+//     one of THREE 2-KiB tail slots, slot = chunk mod 3.  Slot (T+2) mod 3 = (T-1) mod 3 is refilled by DMA pieces that
+//     are issued behind the barrier of tile T; its previous content, the tail of chunk T-1, was read one k-step before
+//     the barrier of tile T-1 and consumed by every wave's last MFMAs of tile T-1 (a wave waits for a fragment before it
+//     multiplies with it), i.e. before that wave ARRIVES at the barrier of tile T.  So no LDS location is ever written
+//     while a read of its previous content can be outstanding, whatever the timing: the only reads in flight across a
+//     barrier target a slot that no DMA piece issued before the NEXT barrier touches.  (LDS returns a wave's reads in
+//     order and nothing else in the tile loop counts on lgkmcnt, so "all but two" is exactly "all but those two".)
 template <int CHUNK_BYTES, bool X3>
 struct Walker {
     const uint8_t* stream;
     uint32_t next_tile;      // first tile of the next chunk to stream
     uint32_t lds_chunks;     // LDS byte address of chunk buffer 0
+    uint32_t lds_tail;       // LDS byte address of tail slot 0 (three slots of two tiles)
     const char* buf0;
+    const char* tail0;
+    int t3;                  // chunk % 3: tail slot of the chunk being consumed
+    uint32_t blk_dst_tail;   // blk_dst for the pieces that go to the tail slot (biased so that piece i lands at base + i KiB)
+    int tail_first;          // first piece of this wave's quarter that goes to the tail slot (wave 3 of a long chunk), else huge
     const float* bias_tab;   // LDS bias table of the current network, 32 floats per chunk
     int chunk;               // index of the chunk being consumed
     int b;                   // buffer holding the chunk being consumed
@@ -264,15 +283,25 @@ struct Walker {
 #endif
 
     __device__ __forceinline__ void start(const uint8_t* s, const float* bias) {
-        stream = s; bias_tab = bias; next_tile = 0; chunk = 0; b = 0;
+        stream = s; bias_tab = bias; next_tile = 0; chunk = 0; b = 0; t3 = 0;
     }
     __device__ __forceinline__ const char* cur() const { return buf0 + b * CHUNK_BYTES; }
     __device__ __forceinline__ const char* next() const { return buf0 + (b ^ 1) * CHUNK_BYTES; }
-    __device__ __forceinline__ void begin(int n_per_wave, int buffer) {
+    __device__ __forceinline__ const char* tail() const { return tail0 + t3 * (2 * kTileBytes); }
+    // Start streaming a chunk of n_per_wave pieces per wave into `buffer`; ahead = how many chunks it is ahead of the one
+    // being consumed (its tail slot is (t3 + ahead) mod 3).
+    __device__ __forceinline__ void begin(int n_per_wave, int buffer, int ahead) {
         blk_src = stream + ((size_t)next_tile + (size_t)wave * n_per_wave) * kTileBytes;
         blk_dst = lds_chunks + buffer * CHUNK_BYTES + wave * n_per_wave * kTileBytes;
         next_tile += n_per_wave * kWaves;
         skip_lo = !X3 && (n_per_wave & 1) == 0;
+        if (X3) {
+            int slot = t3 + ahead;
+            slot = slot >= 3 ? slot - 3 : slot;
+            const bool lng = n_per_wave >= 8;                               // Shape::LONG_PIECES
+            tail_first = (lng && wave == kWaves - 1) ? n_per_wave - 2 : (1 << 20);
+            blk_dst_tail = lds_tail + slot * (2 * kTileBytes) - (n_per_wave - 2) * kTileBytes;
+        }
     }
     // Piece i of the chunk being streamed.  Pieces go in groups of four: one scalar base per group, the 1-KiB step inside
     // a group rides on the instruction offset, which advances the global source AND the LDS destination (nwe_selftest
@@ -286,18 +315,32 @@ struct Walker {
         // streamed nor read; the LDS layout keeps its holes.  (A run-time test, but only in the single-pass instantiation.)
         if (!X3 && skip_lo && (i & 1)) return;
         const uint8_t* src = blk_src + (size_t)(i >> 2) * (4 * kTileBytes);
-        const uint32_t dst = blk_dst + (i >> 2) * (4 * kTileBytes);
-        switch (i & 3) {
+        // the last two pieces of a long chunk (wave 3: n-2, n-1) go to the chunk's tail slot: a scalar select, no branch
+        const uint32_t base = (X3 && i >= tail_first) ? blk_dst_tail : blk_dst;
+        const uint32_t dst = base + (i >> 2) * (4 * kTileBytes);
+        // M0 is written by the first piece of a group and by pieces 6 and 7, one of which is the first tail piece of an
+        // 8- or 9-piece quarter (a 10-piece quarter's first tail piece, 8, opens a group anyway); where neither is, the
+        // write repeats the value M0 already has.
+        const bool set_m0 = (i & 3) == 0 || (X3 && (i == 6 || i == 7));
 #define NWE_GLDS(OFF) asm volatile("global_load_lds_dwordx4 %0, %1 offset:" #OFF :: "v"(lane_off), "s"(src) : "memory")
-            case 0:   // first piece of a group: point M0 at the group's LDS destination (one wait state before the DMA)
-                asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(lane_off), "s"(src), "s"(dst)
-                             : "memory");
-                break;
-            case 1: NWE_GLDS(1024); break;
-            case 2: NWE_GLDS(2048); break;
-            default: NWE_GLDS(3072); break;
-#undef NWE_GLDS
+#define NWE_GLDS_M0(OFF) asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:" #OFF \
+                                      :: "v"(lane_off), "s"(src), "s"(dst) : "memory")
+        if (set_m0) {   // point M0 at the group's LDS destination (one wait state before the DMA)
+            switch (i & 3) {
+                case 0: NWE_GLDS_M0(0); break;
+                case 1: NWE_GLDS_M0(1024); break;
+                case 2: NWE_GLDS_M0(2048); break;
+                default: NWE_GLDS_M0(3072); break;
+            }
+        } else {
+            switch (i & 3) {
+                case 1: NWE_GLDS(1024); break;
+                case 2: NWE_GLDS(2048); break;
+                default: NWE_GLDS(3072); break;
+            }
         }
+#undef NWE_GLDS
+#undef NWE_GLDS_M0
     }
     template <bool LONG_TILE>
     __device__ __forceinline__ void sync() {
@@ -306,16 +349,14 @@ struct Walker {
 #endif
         // Own DMA pieces of chunk T+1 landed and own LDS reads done - on the long tiles EXCEPT the two reads just issued (the
         // fragments of this chunk's last k-step, one k-step ago): waiting for those too costs an LDS round trip per tile
-        // (5 % of the frame time).  They read tiles 2*NQ-2, 2*NQ-1 of the buffer this barrier releases; the pieces that
-        // overwrite those two tiles are the last two of the wave owning the chunk's last quarter and are issued >= 3
-        // k-steps (9 MFMAs, ~300 cycles) into the next tile, while the reads were handed to the LDS unit before the
-        // barrier and the LDS services its queue in order.  Short tiles re-fill the buffer right behind the barrier and
-        // keep the full wait.
+        // (5 % of the frame time).  They read the chunk's tail slot, which this barrier does NOT release (see the
+        // timeline above); everything in the chunk buffer it does release has been read.  Short tiles have no tail slot
+        // and keep the full wait.
         if (LONG_TILE) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(2)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         asm volatile("s_barrier" ::: "memory");
     }
-    __device__ __forceinline__ void tile_done() { b ^= 1; ++chunk; }
+    __device__ __forceinline__ void tile_done() { b ^= 1; ++chunk; t3 = t3 == 2 ? 0 : t3 + 1; }
 };
 
 // Compile-time loop: f(integral_constant<int, I>) for I in [I0, N).
@@ -375,8 +416,10 @@ __device__ __forceinline__ void tile_mma(WalkerT& wk, Frags& F, int lane, bool u
 #pragma unroll
     for (int g = 0; g < 4; ++g) cur.bias[g] = bp[2 * g + h];
     __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+    constexpr bool LONG_TILE = X3 && NQ >= 16;   // the (hi, lo) tiles of the last k-step live in the chunk's tail slot (Walker)
     const char* cbase = wk.cur() + lane * 16;
     const char* nbase = wk.next() + lane * 16;
+    const char* tbase = wk.tail() + lane * 16;
     bool pre_done = false;
     float ekeep = 0.f;   // even element of the epilogue pair in flight (unstaged fallback)
     Epi E;
@@ -416,11 +459,11 @@ __device__ __forceinline__ void tile_mma(WalkerT& wk, Frags& F, int lane, bool u
 #ifdef NWE_STAMPS
             { const unsigned long long t = __builtin_amdgcn_s_memtime(); wk.st_pre += t - wk.st_t0; wk.st_t0 = t; }
 #endif
-            wk.template sync<(X3 && NQ >= 16)>();
+            wk.template sync<LONG_TILE>();
 #ifdef NWE_STAMPS
             { const unsigned long long t = __builtin_amdgcn_s_memtime(); wk.st_wait += t - wk.st_t0; wk.st_t0 = t; }
 #endif
-            if (NA > 0) wk.begin(na_override >= 0 ? na_override : NA + (extraA ? 2 : 0), wk.b);
+            if (NA > 0) wk.begin(na_override >= 0 ? na_override : NA + (extraA ? 2 : 0), wk.b, 2);
         }
         // first MFMA of the k-step (hi.hi); everything else of the k-step is issued behind it, while it executes
         const int use = (PHASE + q) % R;
@@ -447,7 +490,11 @@ __device__ __forceinline__ void tile_mma(WalkerT& wk, Frags& F, int lane, bool u
         };
         if constexpr (!X3) dma();
         // fragment read of position q+PD: this chunk, or the next tile's first k-steps (visible since the barrier)
-        if (q + PD < NQ) {
+        if (LONG_TILE && q + PD == NQ - 1) {
+            const int slot = (PHASE + q + PD) % R;   // the two reads that stay in flight across the barrier: the tail slot
+            F.lo[slot] = *reinterpret_cast<const h8*>(tbase + kTileBytes);
+            F.hi[slot] = *reinterpret_cast<const h8*>(tbase);
+        } else if (q + PD < NQ) {
             const int slot = (PHASE + q + PD) % R;   // lo first: the first MFMA of the k-step needs hi, so one wait covers both
             if (X3) F.lo[slot] = *reinterpret_cast<const h8*>(cbase + (2 * (q + PD) + 1) * kTileBytes);
             F.hi[slot] = *reinterpret_cast<const h8*>(cbase + (2 * (q + PD)) * kTileBytes);
@@ -612,10 +659,16 @@ __device__ __forceinline__ void view_tiles(WalkerT& wk, Frags& F, int lane, cons
 }
 
 // One MLP evaluation for the wave's 32 points.  nerf/models/nerf_model.py:45-83.
-// Trunk layers 1..D-1 and the feature layer run as (D/2) pairs A->B, B->A so that the two activation register
-// sets keep fixed names inside a rolled loop; every tile's epilogue is deferred into the next tile (see Pend).
+// Trunk layers run as pairs A->B, B->A so that the two activation register sets keep fixed names inside a rolled loop;
+// every tile's epilogue is deferred into the next tile (see Pend).
+//
+// FOLD (the product path): _feature_linear has no activation (nerf_model.py:64) and feeds only the view layer (:66-70), so
+// the packer multiplies it into the view layer's weights (nwe_abi.hip: pack_mfma): trunk layers 1..D-1 = D/2 - 1 pairs and
+// one single layer A->B, then _alpha_linear and the folded view layer both read B = h, the rgb head reads the view layer's
+// output in A.  !FOLD evaluates the feature layer as the reference formulates it (D/2 pairs, the last pair's second layer
+// is the feature layer without ReLU; alpha reads B, the view layer A); kept selectable for comparison.
 // On entry chunks 0 and 1 of the stream are visible / in flight and F holds the first PD k-steps of chunk 0.
-template <int W, int D, int SKIP, bool X3, class WalkerT>
+template <int W, int D, int SKIP, bool X3, bool FOLD, class WalkerT>
 __device__ __forceinline__ void mlp_eval(WalkerT& wk, Frags& F, int lane, float inv_scale, h8* Ghi, h8* Glo, const h8* GDhi,
                                          const h8* GDlo, float& o_r, float& o_g, float& o_b, float& o_s) {
     using S = Shape<W, D>;
@@ -635,35 +688,49 @@ __device__ __forceinline__ void mlp_eval(WalkerT& wk, Frags& F, int lane, float 
         const bool use_g = pair == SKIP_PAIR;
         const bool last = pair == NPAIR - 1;
         // first of pair: (gamma +) A -> B, ReLU.  Its first tile finishes the pending last tile of A (ReLU: the
-        // producer is layer 0 or a non-final second-of-pair layer).
+        // producer is layer 0 or a non-final second-of-pair layer).  FOLD: the last pair has only this layer; behind it
+        // come the alpha tile (a chunk of N_H pieces like a trunk layer's) and the view layer, whose chunk size the last
+        // tile needs for the head of chunk T+2.
         layer<S::NT, S::KG, S::KH, X3, true, S::N_H, false>(wk, F, lane, use_g, false, Ghi, Glo, Ahi, Alo, Bhi, Blo, P0, P1, inv_scale,
-                                                            0.f, 0.f);
-        // second of pair: B -> A; the last pair's second layer is _feature_linear (no ReLU, nerf_model.py:64).  After it
-        // comes the next pair's first layer (skip: 2 more pieces) or the alpha tile and then the view layer, whose
-        // chunk size the last feature tile needs for the head of chunk T+2.
+                                                            0.f, 0.f, (FOLD && last) ? S::N_V : -1);
+        if (FOLD && last) break;
+        // second of pair: B -> A; !FOLD: the last pair's second layer is _feature_linear (no ReLU, nerf_model.py:64).
+        // After it comes the next pair's first layer (skip: 2 more pieces) or the alpha tile and then the view layer.
         layer<S::NT, 0, S::KH, X3, true, S::N_H, false>(wk, F, lane, false, !last && pair + 1 == SKIP_PAIR, nullptr, nullptr, Bhi, Blo,
-                                                        Ahi, Alo, P0, P1, inv_scale, 0.f, last ? -INFINITY : 0.f, last ? S::N_V : -1);
+                                                        Ahi, Alo, P0, P1, inv_scale, 0.f, (!FOLD && last) ? -INFINITY : 0.f,
+                                                        (!FOLD && last) ? S::N_V : -1);
     }
     constexpr int L = 2 * S::NT - 2;
-    // _alpha_linear on B, the input of _feature_linear (nerf_model.py:63); meanwhile the last feature tile (P1) is
-    // finished into A without ReLU.  Rows 0 and 4 of the alpha tile both hold the single output row.
-    tile_mma<0, S::KH, 0, 0, X3, true, S::N_V, S::N_V, true>(wk, F, lane, false, false, false, nullptr, nullptr, Bhi, Blo, nullptr, nullptr,
-                                                             P0, P1, inv_scale, -INFINITY, Ahi[L], Alo[L], Ahi[L + 1], Alo[L + 1]);
-    const float sigma = pend_value(P0, 0, inv_scale);
-    // view layer: [feature (A), gamma(d)] -> B[0..KV), ReLU (nerf_model.py:66-70)
-    view_tiles<0, W, D, X3>(wk, F, lane, Ahi, Alo, GDhi, GDlo, Bhi, Blo, P0, P1, inv_scale);
-    // rgb head (nerf_model.py:74) in P1 while the last view tile (P0, NTV even) is finished into B; rows 0..2 and
-    // their copies 4..6 for the upper lane half.  Nothing is streamed behind it: the caller starts the next pass.
-    {
-        constexpr int LV = 2 * S::NTV - 2;
-        static_assert((S::NTV * (S::KH + S::KD)) % (PD + 1) == 0, "the view tiles must restore the ring phase");
+    constexpr int LV = 2 * S::NTV - 2;
+    static_assert((S::NTV * (S::KH + S::KD)) % (PD + 1) == 0, "the view tiles must restore the ring phase");
+    if constexpr (FOLD) {
+        // _alpha_linear on B = h (nerf_model.py:63); its first k-steps overlap the epilogue of the last trunk tile (P1),
+        // whose outputs are the last two k-steps of B itself (ReLU).  Rows 0 and 4 of the alpha tile hold the output row.
+        tile_mma<0, S::KH, 0, 0, X3, true, S::N_V, S::N_V, true, true>(wk, F, lane, false, false, false, nullptr, nullptr, Bhi, Blo, nullptr,
+                                                                       nullptr, P0, P1, inv_scale, 0.f, Bhi[L], Blo[L], Bhi[L + 1], Blo[L + 1]);
+        const float sigma = pend_value(P0, 0, inv_scale);
+        // folded view layer: [h (B), gamma(d)] -> A[0..KV), ReLU (nerf_model.py:64-70 with W_v[:, :W] . W_f multiplied out)
+        view_tiles<0, W, D, X3>(wk, F, lane, Bhi, Blo, GDhi, GDlo, Ahi, Alo, P0, P1, inv_scale);
+        // rgb head (nerf_model.py:74) in P1 while the last view tile (P0, NTV even) is finished into A; rows 0..2 and
+        // their copies 4..6 for the upper lane half.  Nothing is streamed behind it: the caller starts the next pass.
+        tile_mma<0, S::KV, 0, 0, X3, true, 0, 0, false, true>(wk, F, lane, false, false, false, nullptr, nullptr, Ahi, Alo, nullptr, nullptr, P1,
+                                                              P0, inv_scale, 0.f, Ahi[LV], Alo[LV], Ahi[LV + 1], Alo[LV + 1]);
+        o_s = sigma;
+    } else {
+        // _alpha_linear on B, the input of _feature_linear (nerf_model.py:63); meanwhile the last feature tile (P1) is
+        // finished into A without ReLU.  Rows 0 and 4 of the alpha tile both hold the single output row.
+        tile_mma<0, S::KH, 0, 0, X3, true, S::N_V, S::N_V, true>(wk, F, lane, false, false, false, nullptr, nullptr, Bhi, Blo, nullptr, nullptr,
+                                                                 P0, P1, inv_scale, -INFINITY, Ahi[L], Alo[L], Ahi[L + 1], Alo[L + 1]);
+        const float sigma = pend_value(P0, 0, inv_scale);
+        // view layer: [feature (A), gamma(d)] -> B[0..KV), ReLU (nerf_model.py:66-70)
+        view_tiles<0, W, D, X3>(wk, F, lane, Ahi, Alo, GDhi, GDlo, Bhi, Blo, P0, P1, inv_scale);
         tile_mma<0, S::KV, 0, 0, X3, true, 0, 0, false, true>(wk, F, lane, false, false, false, nullptr, nullptr, Bhi, Blo, nullptr, nullptr, P1,
-                                                        P0, inv_scale, 0.f, Bhi[LV], Blo[LV], Bhi[LV + 1], Blo[LV + 1]);
+                                                              P0, inv_scale, 0.f, Bhi[LV], Blo[LV], Bhi[LV + 1], Blo[LV + 1]);
+        o_s = sigma;
     }
     o_r = pend_value(P1, 0, inv_scale);
     o_g = pend_value(P1, 1, inv_scale);
     o_b = pend_value(P1, 2, inv_scale);
-    o_s = sigma;
 }
 
 constexpr int kMfmaMaxSamples = 64;   // coarse samples the per-wave LDS weight buffer is sized for
@@ -677,8 +744,9 @@ struct Smem {
     static constexpr int WOFF = BOFF + 2 * BIAS_BYTES;                               // per-wave coarse weights / cdf
     static constexpr int TOFF = WOFF + kWaves * kMfmaMaxSamples * kRaysPerWave * 4;  // t, 1-t, u tables
     static constexpr int XOFF = TOFF + (2 * kMfmaMaxSamples + kMaxImportance) * 4;     // sample-split mode: shaded samples, 2 buffers
-    static constexpr int TOTAL = XOFF + 2 * kWaves * kRaysPerWave * 16;
-    static_assert(XOFF % 16 == 0 && TOTAL <= 160 * 1024, "LDS budget");
+    static constexpr int LOFF = XOFF + 2 * kWaves * kRaysPerWave * 16;               // three tail slots of two tiles (Walker)
+    static constexpr int TOTAL = LOFF + 3 * 2 * kTileBytes;
+    static_assert(XOFF % 16 == 0 && LOFF % 16 == 0 && TOTAL <= 160 * 1024, "LDS budget");
 };
 
 // Two work decompositions, same arithmetic in the same order (results are bit-identical):
@@ -688,7 +756,7 @@ struct Smem {
 //                  sampling for all samples (a few dozen VALU ops per sample, redundantly).  The scheduling unit is a
 //                  quarter of the rays and a quarter of the iterations: a 320x240 frame fills the last round of
 //                  workgroups 17 % better, a 64x64 frame runs 3x faster; launch_t() picks per launch.
-template <int W, int D, int SKIP, bool X3, bool SPLIT>
+template <int W, int D, int SKIP, bool X3, bool SPLIT, bool FOLD>
 __global__ void __launch_bounds__(256) render_mfma_kernel(RenderArgs a, NetMfma nc, NetMfma nf) {
     using S = Shape<W, D>;
     using SM = Smem<W, D>;
@@ -705,20 +773,25 @@ __global__ void __launch_bounds__(256) render_mfma_kernel(RenderArgs a, NetMfma 
     for (int i = threadIdx.x; i < ns; i += 256) { s_t[i] = a.t_vals[i]; s_omt[i] = a.omt_vals[i]; }
     for (int i = threadIdx.x; i < ni; i += 256) s_u[i] = a.u_vals[i];
     float* s_bias = reinterpret_cast<float*>(smem + SM::BOFF);
-    for (int i = threadIdx.x; i < S::N_CHUNKS * 32; i += 256) {
+    constexpr int NCH = FOLD ? S::N_CHUNKS_FOLDED : S::N_CHUNKS;   // the launcher checks n_chunks of both networks against it
+    for (int i = threadIdx.x; i < NCH * 32; i += 256) {
         s_bias[i] = nc.bias[i];
         if (ni > 0) s_bias[SM::BIAS_BYTES / 4 + i] = nf.bias[i];
     }
 
     const int64_t packet = SPLIT ? (int64_t)blockIdx.x : (int64_t)blockIdx.x * kWaves + wave;
-    const int64_t ridx = a.ray_first + packet * kRaysPerWave + (lane & 31);
-    const bool lane_live = ridx < a.n_rays && half == 0;      // this lane stores per-sample outputs of its ray
+    const int64_t ridx64 = a.ray_first + packet * kRaysPerWave + (lane & 31);
+    const bool lane_live = ridx64 < a.n_rays && half == 0;    // this lane stores per-sample outputs of its ray
     const bool live = lane_live && (!SPLIT || wave == 0);      // ... and the per-ray results (every wave holds them in SPLIT mode)
-    const int64_t rclamp = ridx < a.n_rays ? ridx : a.n_rays - 1;
+    // One 32-bit row index per lane (the ABI keeps n_rays below 2^31): the ray's own index, or the call's last ray for the
+    // lanes of a ragged last packet, which compute along and store nothing.  64-bit only where an offset is formed.
+    const int row = (int)(ridx64 < a.n_rays ? ridx64 : a.n_rays - 1);
+    const int64_t ridx = row, rclamp = row;
     const Ray ray = load_ray(a, rclamp);
 
     Walker<S::CHUNK_BYTES, X3> wk;
     wk.buf0 = smem; wk.lds_chunks = (uint32_t)(uintptr_t)(LDS_AS char*)smem;
+    wk.tail0 = smem + SM::LOFF; wk.lds_tail = wk.lds_chunks + SM::LOFF; wk.t3 = 0;
     wk.b = 0; wk.wave = wave; wk.lane_off = lane * 16;
 
     // gamma(d): once per ray (model_utils.py:23-25 re-embeds the same direction for every sample)
@@ -729,8 +802,8 @@ __global__ void __launch_bounds__(256) render_mfma_kernel(RenderArgs a, NetMfma 
     fs.wc = reinterpret_cast<float*>(smem + SM::WOFF) + wave * (kMfmaMaxSamples * kRaysPerWave) + (lane & 31);
     fs.stride = kRaysPerWave; fs.u_tab = s_u; fs.ns = ns; fs.ni = ni;
     fs.cd.t_tab = s_t; fs.cd.omt_tab = s_omt; fs.cd.ns = ns;
-    fs.cd.jitter = a.t_rand ? a.t_rand + rclamp * ns : nullptr;       // training-mode forward: host-drawn random rows
-    fs.u_row = a.u_rand ? a.u_rand + rclamp * ni : nullptr;
+    fs.cd.jitter = a.t_rand; fs.cd.row = row;                         // training-mode forward: host-drawn random rows
+    fs.u_rand = a.u_rand;
     __syncthreads();
 
     Composite comp;
@@ -744,6 +817,11 @@ __global__ void __launch_bounds__(256) render_mfma_kernel(RenderArgs a, NetMfma 
         const float* bias = s_bias + (pass == 0 ? 0 : SM::BIAS_BYTES / 4);
         const int Stot = pass == 0 ? ns : ns + ni;
         const float* noise = pass == 0 ? a.noise_c : a.noise_f;
+        const float* raw_in = pass == 0 ? a.raw_in_c : a.raw_in_f;   // test hook: network outputs from the caller (uniform)
+        if (pass == 0 && a.w_in) {                                   // test hook: coarse weights from the caller, no coarse pass
+            for (int s = 0; s < ns; ++s) fs.wc[s * kRaysPerWave] = a.w_in[rclamp * ns + s];
+            continue;
+        }
         comp.reset();
         if constexpr (SPLIT) {
             // depths are produced strictly in order: zq[0..3] = this iteration's four samples, zq[4] = the first of the next
@@ -754,7 +832,13 @@ __global__ void __launch_bounds__(256) render_mfma_kernel(RenderArgs a, NetMfma 
                 if (pass == 0) return fs.cd.z(ray, i);
                 return a.z_fine_in ? a.z_fine_in[rclamp * Stot + i] : fs.next(ray);
             };
-            if (pass == 1) fs.prepare(ray);
+            if (pass == 1) {
+                fs.prepare(ray);
+                if (wants_survey(a.out)) {
+                    const SampleSurvey sv = fs.survey(ray);
+                    if (live) flags |= store_survey(a.out, ridx, sv);
+                }
+            }
             float zq[5], zp[4];
 #pragma unroll
             for (int k = 0; k < 5; ++k) zq[k] = gen();
@@ -768,7 +852,10 @@ __global__ void __launch_bounds__(256) render_mfma_kernel(RenderArgs a, NetMfma 
                     const int si = 4 * it + k;
                     if (si < Stot) {
                         const float w = comp.accumulate(x[k * kRaysPerWave], zp[k]);
-                        if (pass == 0) fs.wc[si * kRaysPerWave] = w;
+                        if (pass == 0) {
+                            fs.wc[si * kRaysPerWave] = w;
+                            if (live && a.out.weights_coarse) a.out.weights_coarse[ridx * ns + si] = w;
+                        }
                     }
                 }
             };
@@ -776,13 +863,15 @@ __global__ void __launch_bounds__(256) render_mfma_kernel(RenderArgs a, NetMfma 
 #ifdef NWE_STAMPS
                 const unsigned long long t0 = __builtin_amdgcn_s_memtime();
 #endif
-                wk.start(net.stream, bias);
-                wk.begin(S::N_L0, 0);
+                if (!raw_in) {
+                    wk.start(net.stream, bias);
+                    wk.begin(S::N_L0, 0, 0);
 #pragma unroll
-                for (int i = 0; i < S::N_L0; ++i) wk.piece(i);
-                wk.begin(S::N_L0, 1);
+                    for (int i = 0; i < S::N_L0; ++i) wk.piece(i);
+                    wk.begin(S::N_L0, 1, 1);
 #pragma unroll
-                for (int i = 0; i < S::N_L0; ++i) wk.piece(i);
+                    for (int i = 0; i < S::N_L0; ++i) wk.piece(i);
+                }
                 const int s_own = 4 * it + wave;
                 const bool own_valid = s_own < Stot;
                 float z_own = zq[0], z_nxt = zq[1];
@@ -792,12 +881,22 @@ __global__ void __launch_bounds__(256) render_mfma_kernel(RenderArgs a, NetMfma 
                 float nz[4];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) nz[k] = gen();
+                float rr, rg, rb, rs;
+                if (raw_in) {
+                    __syncthreads();             // publishes the previous iteration's shaded samples
+                    if (it > 0) drain(it - 1);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) zp[k] = zq[k];
+                    const float4 v = *reinterpret_cast<const float4*>(raw_in + (rclamp * Stot + (own_valid ? s_own : Stot - 1)) * 4);
+                    rr = v.x; rg = v.y; rb = v.z; rs = v.w;
+                } else {
                 float px, py, pz;
                 point_at(ray, z_own, px, py, pz);
                 h8 Ghi[S::KG], Glo[S::KG];
                 encode<5, S::KG, X3>(__fdiv_rn(px, 10.f), __fdiv_rn(py, 10.f), __fdiv_rn(pz, 10.f), half, Ghi, Glo);
 #ifdef NWE_STAMPS
                 const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+                st_enc += t1 - t0;
 #endif
                 wk.template sync<false>();   // also publishes the previous iteration's shaded samples
                 Frags F;
@@ -812,9 +911,13 @@ __global__ void __launch_bounds__(256) render_mfma_kernel(RenderArgs a, NetMfma 
 #ifdef NWE_STAMPS
                 const unsigned long long t2 = __builtin_amdgcn_s_memtime();
                 wk.st_t0 = t2;
+                st_sync += t2 - t1;
 #endif
-                float rr, rg, rb, rs;
-                mlp_eval<W, D, SKIP, X3>(wk, F, lane, net.inv_scale, Ghi, Glo, GDhi, GDlo, rr, rg, rb, rs);
+                mlp_eval<W, D, SKIP, X3, FOLD>(wk, F, lane, net.inv_scale, Ghi, Glo, GDhi, GDlo, rr, rg, rb, rs);
+#ifdef NWE_STAMPS
+                st_mlp += __builtin_amdgcn_s_memtime() - t2;
+#endif
+                }
 #ifdef NWE_STAMPS
                 const unsigned long long t3 = __builtin_amdgcn_s_memtime();
 #endif
@@ -834,8 +937,7 @@ __global__ void __launch_bounds__(256) render_mfma_kernel(RenderArgs a, NetMfma 
 #pragma unroll
                 for (int k = 0; k < 4; ++k) zq[k + 1] = nz[k];
 #ifdef NWE_STAMPS
-                const unsigned long long t4 = __builtin_amdgcn_s_memtime();
-                st_enc += t1 - t0; st_sync += t2 - t1; st_mlp += t3 - t2; st_comp += t4 - t3;
+                st_comp += __builtin_amdgcn_s_memtime() - t3;
 #endif
             }
             __syncthreads();
@@ -846,6 +948,10 @@ __global__ void __launch_bounds__(256) render_mfma_kernel(RenderArgs a, NetMfma 
             if (pass == 0) z_cur = fs.cd.z(ray, 0);
             else {
                 fs.prepare(ray);
+                if (wants_survey(a.out)) {
+                    const SampleSurvey sv = fs.survey(ray);
+                    if (live) flags |= store_survey(a.out, ridx, sv);
+                }
                 z_cur = a.z_fine_in ? a.z_fine_in[rclamp * Stot] : fs.next(ray);
             }
             for (int s = 0; s < Stot; ++s) {
@@ -853,17 +959,24 @@ __global__ void __launch_bounds__(256) render_mfma_kernel(RenderArgs a, NetMfma 
                 const unsigned long long t0 = __builtin_amdgcn_s_memtime();
     #endif
                 // chunks 0 and 1 (layer 0, tiles 0 and 1) fly while the sample's depth and gamma(x) are computed
-                wk.start(net.stream, bias);
-                wk.begin(S::N_L0, 0);
+                if (!raw_in) {
+                    wk.start(net.stream, bias);
+                    wk.begin(S::N_L0, 0, 0);
     #pragma unroll
-                for (int i = 0; i < S::N_L0; ++i) wk.piece(i);
-                wk.begin(S::N_L0, 1);
+                    for (int i = 0; i < S::N_L0; ++i) wk.piece(i);
+                    wk.begin(S::N_L0, 1, 1);
     #pragma unroll
-                for (int i = 0; i < S::N_L0; ++i) wk.piece(i);
+                    for (int i = 0; i < S::N_L0; ++i) wk.piece(i);
+                }
                 if (s + 1 < Stot) {
                     if (pass == 0) z_next = fs.cd.z(ray, s + 1);
                     else z_next = a.z_fine_in ? a.z_fine_in[rclamp * Stot + s + 1] : fs.next(ray);
                 }
+                float rr, rg, rb, rs;
+                if (raw_in) {
+                    const float4 v = *reinterpret_cast<const float4*>(raw_in + (rclamp * Stot + s) * 4);
+                    rr = v.x; rg = v.y; rb = v.z; rs = v.w;
+                } else {
                 float px, py, pz;
                 point_at(ray, z_cur, px, py, pz);
                 h8 Ghi[S::KG], Glo[S::KG];
@@ -871,6 +984,7 @@ __global__ void __launch_bounds__(256) render_mfma_kernel(RenderArgs a, NetMfma 
                 encode<5, S::KG, X3>(__fdiv_rn(px, 10.f), __fdiv_rn(py, 10.f), __fdiv_rn(pz, 10.f), half, Ghi, Glo);
     #ifdef NWE_STAMPS
                 const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+                st_enc += t1 - t0;
     #endif
                 wk.template sync<false>();
                 Frags F;
@@ -882,15 +996,20 @@ __global__ void __launch_bounds__(256) render_mfma_kernel(RenderArgs a, NetMfma 
     #ifdef NWE_STAMPS
                 const unsigned long long t2 = __builtin_amdgcn_s_memtime();
                 wk.st_t0 = t2;
+                st_sync += t2 - t1;
     #endif
-                float rr, rg, rb, rs;
-                mlp_eval<W, D, SKIP, X3>(wk, F, lane, net.inv_scale, Ghi, Glo, GDhi, GDlo, rr, rg, rb, rs);
+                mlp_eval<W, D, SKIP, X3, FOLD>(wk, F, lane, net.inv_scale, Ghi, Glo, GDhi, GDlo, rr, rg, rb, rs);
+    #ifdef NWE_STAMPS
+                st_mlp += __builtin_amdgcn_s_memtime() - t2;
+    #endif
+                }
     #ifdef NWE_STAMPS
                 const unsigned long long t3 = __builtin_amdgcn_s_memtime();
     #endif
                 const float w = comp.step(rr, rg, rb, rs, z_cur, z_next, s + 1 == Stot, ray.dnorm, noise ? noise[rclamp * Stot + s] : 0.f);
                 if (pass == 0) fs.wc[s * kRaysPerWave] = w;
                 if (lane_live) {
+                    if (pass == 0 && a.out.weights_coarse) a.out.weights_coarse[ridx * ns + s] = w;
                     float* raw = pass == 0 ? a.out.raw_coarse : a.out.raw_fine;
                     if (raw) {
                         *reinterpret_cast<float4*>(raw + (ridx * Stot + s) * 4) = make_float4(rr, rg, rb, rs);
@@ -900,20 +1019,13 @@ __global__ void __launch_bounds__(256) render_mfma_kernel(RenderArgs a, NetMfma 
                 }
                 z_cur = z_next;
     #ifdef NWE_STAMPS
-                const unsigned long long t4 = __builtin_amdgcn_s_memtime();
-                st_enc += t1 - t0; st_sync += t2 - t1; st_mlp += t3 - t2; st_comp += t4 - t3;
+                st_comp += __builtin_amdgcn_s_memtime() - t3;
     #endif
             }
         }
         if (live) {
             flags |= store_ray(a.out, ridx, comp, pass == 1, a.white_bkgd != 0);
             if (ni == 0) flags |= store_ray(a.out, ridx, comp, true, a.white_bkgd != 0);
-            if (pass == 1 && a.out.z_std) {
-                const float zs = fs.z_std();
-                a.out.z_std[ridx] = zs;
-                if (bad(zs)) flags |= NWE_FLAG_ZSTD;
-            }
-            if (pass == 1 && a.out.sample_cond) a.out.sample_cond[ridx] = fs.min_denom;
         }
     }
     if (flags && a.out.flags) atomicOr(a.out.flags, flags);
@@ -926,15 +1038,19 @@ __global__ void __launch_bounds__(256) render_mfma_kernel(RenderArgs a, NetMfma 
 #endif
 }
 
-bool mfma_supported(int D, int W, int in_xyz, int in_dir, int skip) {
-    if (in_xyz != 63 || in_dir != 27) return false;
-    return (D == 8 && W == 256 && skip == 4) || (D == 4 && W == 128 && skip == -1) || (D == 8 && W == 128 && skip == 4) ||
-           (D == 4 && W == 256 && skip == -1);
+// Instantiated shapes: width 128 or 256, even depth 4 / 6 / 8 with the reference's skip connection (after layer 4 where
+// that layer exists and feeds another trunk layer, nerf_model.py:13,58-59; none for depth 4), 63/27-wide encodings.
+// The unfolded formulation (!FOLD) exists for the two BASELINE shapes only.
+bool mfma_supported(int D, int W, int in_xyz, int in_dir, int skip, bool folded) {
+    if (in_xyz != 63 || in_dir != 27 || (W != 128 && W != 256)) return false;
+    const bool shape = (D == 8 && skip == 4) || (D == 6 && skip == 4) || (D == 4 && skip == -1);
+    if (!shape) return false;
+    return folded || (D == 8 && W == 256) || (D == 4 && W == 128);
 }
 
 int mfma_max_samples() { return kMfmaMaxSamples; }
 
-template <int W, int D, int SKIP>
+template <int W, int D, int SKIP, bool FOLD>
 static void launch_one(RenderArgs a, const NetMfma& nc, const NetMfma& nf, bool three_pass, bool split, int64_t ray_first, int64_t rays,
                        hipStream_t stream) {
     if (rays <= 0) return;
@@ -942,16 +1058,19 @@ static void launch_one(RenderArgs a, const NetMfma& nc, const NetMfma& nf, bool 
     const int64_t per_wg = split ? kRaysPerWave : kWaves * kRaysPerWave;
     const unsigned blocks = (unsigned)((rays + per_wg - 1) / per_wg);
     if (three_pass) {
-        if (split) hipLaunchKernelGGL((render_mfma_kernel<W, D, SKIP, true, true>), dim3(blocks), dim3(256), 0, stream, a, nc, nf);
-        else hipLaunchKernelGGL((render_mfma_kernel<W, D, SKIP, true, false>), dim3(blocks), dim3(256), 0, stream, a, nc, nf);
+        if (split) hipLaunchKernelGGL((render_mfma_kernel<W, D, SKIP, true, true, FOLD>), dim3(blocks), dim3(256), 0, stream, a, nc, nf);
+        else hipLaunchKernelGGL((render_mfma_kernel<W, D, SKIP, true, false, FOLD>), dim3(blocks), dim3(256), 0, stream, a, nc, nf);
     } else {
-        if (split) hipLaunchKernelGGL((render_mfma_kernel<W, D, SKIP, false, true>), dim3(blocks), dim3(256), 0, stream, a, nc, nf);
-        else hipLaunchKernelGGL((render_mfma_kernel<W, D, SKIP, false, false>), dim3(blocks), dim3(256), 0, stream, a, nc, nf);
+        if (split) hipLaunchKernelGGL((render_mfma_kernel<W, D, SKIP, false, true, FOLD>), dim3(blocks), dim3(256), 0, stream, a, nc, nf);
+        else hipLaunchKernelGGL((render_mfma_kernel<W, D, SKIP, false, false, FOLD>), dim3(blocks), dim3(256), 0, stream, a, nc, nf);
     }
 }
 
-template <int W, int D, int SKIP>
-static void launch_t(const RenderArgs& a, const NetMfma& nc, const NetMfma& nf, bool three_pass, int decomposition, hipStream_t stream) {
+template <int W, int D, int SKIP, bool FOLD>
+static bool launch_t(const RenderArgs& a, const NetMfma& nc, const NetMfma& nf, bool three_pass, int decomposition, hipStream_t stream) {
+    using S = Shape<W, D>;
+    constexpr int NCH = FOLD ? S::N_CHUNKS_FOLDED : S::N_CHUNKS;
+    if (nc.n_chunks != NCH || (a.n_importance > 0 && nf.n_chunks != NCH)) return false;   // the kernel copies NCH bias rows
     // One workgroup per CU at a time, so a launch costs (rounds of workgroups) x (sample iterations per workgroup).  Three
     // plans, same arithmetic: all packets; all sample-split (finer units, ~6 % overhead: redundant sequential part and
     // exchange); or the full rounds as packets and the ragged last round sample-split in a second launch behind it.
@@ -971,22 +1090,30 @@ static void launch_t(const RenderArgs& a, const NetMfma& nc, const NetMfma& nf, 
     int plan = t_hybrid < 0.97 * t_single ? 2 : (t_packet <= t_split ? 0 : 1);
     if (decomposition >= 0) plan = decomposition;   // nwe_debug_set_decomposition: tests force one
     if (plan == 2) {
-        launch_one<W, D, SKIP>(a, nc, nf, three_pass, false, 0, full, stream);
-        launch_one<W, D, SKIP>(a, nc, nf, three_pass, true, full, a.n_rays - full, stream);
+        launch_one<W, D, SKIP, FOLD>(a, nc, nf, three_pass, false, 0, full, stream);
+        launch_one<W, D, SKIP, FOLD>(a, nc, nf, three_pass, true, full, a.n_rays - full, stream);
     } else {
-        launch_one<W, D, SKIP>(a, nc, nf, three_pass, plan == 1, 0, a.n_rays, stream);
+        launch_one<W, D, SKIP, FOLD>(a, nc, nf, three_pass, plan == 1, 0, a.n_rays, stream);
     }
+    return true;
 }
 
 bool launch_render_mfma(const RenderArgs& a, const NetMfma& nc, const NetMfma& nf, bool three_pass, int decomposition, hipStream_t stream) {
-    if (a.n_importance > 0 && (nf.D != nc.D || nf.W != nc.W || nf.skip != nc.skip)) return false;
+    if (a.n_importance > 0 && (nf.D != nc.D || nf.W != nc.W || nf.skip != nc.skip || nf.folded != nc.folded)) return false;
     if (a.n_samples > kMfmaMaxSamples) return false;
-    if (nc.D == 8 && nc.W == 256 && nc.skip == 4) launch_t<256, 8, 4>(a, nc, nf, three_pass, decomposition, stream);
-    else if (nc.D == 4 && nc.W == 128 && nc.skip == -1) launch_t<128, 4, -1>(a, nc, nf, three_pass, decomposition, stream);
-    else if (nc.D == 8 && nc.W == 128 && nc.skip == 4) launch_t<128, 8, 4>(a, nc, nf, three_pass, decomposition, stream);
-    else if (nc.D == 4 && nc.W == 256 && nc.skip == -1) launch_t<256, 4, -1>(a, nc, nf, three_pass, decomposition, stream);
-    else return false;
-    return true;
+    const int D = nc.D, W = nc.W, skip = nc.skip;
+    if (nc.folded) {
+        if (D == 8 && W == 256 && skip == 4) return launch_t<256, 8, 4, true>(a, nc, nf, three_pass, decomposition, stream);
+        if (D == 4 && W == 128 && skip == -1) return launch_t<128, 4, -1, true>(a, nc, nf, three_pass, decomposition, stream);
+        if (D == 8 && W == 128 && skip == 4) return launch_t<128, 8, 4, true>(a, nc, nf, three_pass, decomposition, stream);
+        if (D == 4 && W == 256 && skip == -1) return launch_t<256, 4, -1, true>(a, nc, nf, three_pass, decomposition, stream);
+        if (D == 6 && W == 256 && skip == 4) return launch_t<256, 6, 4, true>(a, nc, nf, three_pass, decomposition, stream);
+        if (D == 6 && W == 128 && skip == 4) return launch_t<128, 6, 4, true>(a, nc, nf, three_pass, decomposition, stream);
+        return false;
+    }
+    if (D == 8 && W == 256 && skip == 4) return launch_t<256, 8, 4, false>(a, nc, nf, three_pass, decomposition, stream);
+    if (D == 4 && W == 128 && skip == -1) return launch_t<128, 4, -1, false>(a, nc, nf, three_pass, decomposition, stream);
+    return false;
 }
 
 }  // namespace nwe

@@ -87,6 +87,10 @@ class NeRFReplicaInferenceHandler:
         if self._renderer is not None:
             self._renderer.set_sampling(n_samples, n_importance)
 
+    def debug_set_fold(self, on: bool) -> None:
+        """Test hook (Renderer.debug_set_fold): applies to the networks the next initialize_models() uploads."""
+        self._fold = bool(on)
+
     def initialize_models(self, state_dicts: Optional[Tuple[Mapping, Mapping]] = None) -> None:
         """Load the checkpoint and upload both networks (handler.py:88-148).  Safe to call repeatedly
         (the GUI calls it on every window open, application/app.py:116).  ``state_dicts=(coarse, fine)``
@@ -98,6 +102,8 @@ class NeRFReplicaInferenceHandler:
                 raise RuntimeError(f"Checkpoint path: {self._ckpt_path} for model cannot be found!") from exc
         if self._renderer is None:
             self._renderer = Renderer(self._device_index)
+        if getattr(self, "_fold", True) is False:
+            self._renderer.debug_set_fold(False)
         coarse, fine = state_dicts
         self._renderer.set_network(_lib.NET_COARSE, coarse)
         if fine is not None:

@@ -16,7 +16,7 @@ from . import _lib
 LAYER_ORDER_TAIL = ("_views_linears.0", "_feature_linear", "_alpha_linear", "_rgb_linear")
 
 _PER_RAY = {"rgb": 3, "depth": 1, "acc": 1, "disp": 1, "z_std": 1, "rgb_coarse": 3, "depth_coarse": 1,
-            "acc_coarse": 1, "disp_coarse": 1, "sample_cond": 1}
+            "acc_coarse": 1, "disp_coarse": 1, "sample_cond": 1, "sample_amp": 1, "sample_switch": 1}
 
 
 def normalize_state_dict(sd: Mapping[str, object]) -> Dict[str, np.ndarray]:
@@ -119,6 +119,8 @@ class Renderer:
         for name in outputs:
             if name in _PER_RAY:
                 shape = (n_rays, 3) if _PER_RAY[name] == 3 else (n_rays,)
+            elif name == "weights_coarse":
+                shape = (n_rays, self.n_samples)
             elif name == "raw_coarse":
                 shape = (n_rays, self.n_samples, 4)
             elif name == "raw_fine":
@@ -165,9 +167,13 @@ class Renderer:
     def render_rays(self, rays: torch.Tensor, *, precision: str = "f16x3",
                     outputs: Sequence[str] = ("rgb", "depth", "acc"),
                     debug_fine_depths: Optional[torch.Tensor] = None,
+                    debug_raw: Optional[Tuple[Optional[torch.Tensor], Optional[torch.Tensor]]] = None,
+                    debug_coarse_weights: Optional[torch.Tensor] = None,
                     train: Optional[Dict[str, Optional[torch.Tensor]]] = None) -> Dict[str, torch.Tensor]:
         """rays: [R,11] fp32 on this renderer's device, the layout of nerf/rays/rays.py:26-30.
-        ``debug_fine_depths`` ([R, Ns+Ni], test hook) replaces the importance sampling of the fine pass.
+        ``debug_fine_depths`` ([R, Ns+Ni], test hook) replaces the importance sampling of the fine pass;
+        ``debug_raw`` = (raw_coarse [R,Ns,4] or None, raw_fine [R,Ns+Ni,4] or None) replaces the MLP outputs;
+        ``debug_coarse_weights`` [R,Ns] replaces the coarse pass (its outputs are then not written).
 
         ``train`` switches on the training-mode forward of nerf/training/nerf_replica_training_handler.py:553-580 with
         random numbers drawn by the caller where the reference draws them (any key may be missing / None):
@@ -183,6 +189,25 @@ class Renderer:
                 raise ValueError("debug_fine_depths must be [R, n_samples + n_importance]")
             self._lib.nwe_debug_set_fine_depths(self._ctx, debug_fine_depths.data_ptr())
         keep = []
+        S = self.n_samples + self.n_importance
+        if debug_raw is not None:
+            ptrs = []
+            for t, n in zip(debug_raw, (self.n_samples, S)):
+                if t is None:
+                    ptrs.append(None)
+                    continue
+                t = t.to(self.device, torch.float32).contiguous()
+                if tuple(t.shape) != (rays.shape[0], n, 4):
+                    raise ValueError(f"debug_raw entries must be [R, {n}, 4]")
+                keep.append(t)
+                ptrs.append(t.data_ptr())
+            self._lib.nwe_debug_set_raw(self._ctx, *ptrs)
+        if debug_coarse_weights is not None:
+            t = debug_coarse_weights.to(self.device, torch.float32).contiguous()
+            if tuple(t.shape) != (rays.shape[0], self.n_samples):
+                raise ValueError("debug_coarse_weights must be [R, n_samples]")
+            keep.append(t)
+            self._lib.nwe_debug_set_coarse_weights(self._ctx, t.data_ptr())
         if train:
             R, ns, ni = rays.shape[0], self.n_samples, self.n_importance
             shapes = {"t_rand": (R, ns), "noise_coarse": (R, ns), "noise_fine": (R, ns + ni), "u": (R, ni)}
@@ -215,6 +240,11 @@ class Renderer:
         if debug_fine_depths is not None:
             res["_keepalive_depths"] = debug_fine_depths
         return res
+
+    def debug_set_fold(self, on: bool) -> None:
+        """Test hook: networks uploaded after this call are packed with (default) / without _feature_linear folded into the
+        view layer (include/nwe.h)."""
+        self._check(self._lib.nwe_debug_set_fold(self._ctx, 1 if on else 0), "nwe_debug_set_fold")
 
     def debug_set_decomposition(self, mode: int) -> None:
         """Test hook: 0 = four ray packets per workgroup, 1 = sample split, 2 = packets for the full rounds + sample split for the

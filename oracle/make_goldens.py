@@ -244,6 +244,11 @@ def main() -> None:
         e2e[f"sigma_last_coarse_{name}"] = ref["raw_coarse"][:, -1, 3].numpy()
         e2e[f"raw_fine_first64_{name}"] = ref["raw_fine"][:64].numpy()
         e2e[f"z_fine_first64_{name}"] = ref["z_fine"][:64].numpy()
+        # the link between the coarse and the fine pass, every ray: what raw2outputs returns 4th (model_utils.py:80) and
+        # what sample_pdf makes of it (handler.py:237), so that the sampler is checked on its own inputs and every
+        # end-to-end deviation can be attributed ray by ray
+        e2e[f"weights_coarse_{name}"] = ref["weights_coarse"].numpy()
+        e2e[f"z_samples_{name}"] = ref["z_samples"].numpy()
         rgb = ref["rgb_fine"]
         print(f"    {name}: rgb range {rgb.min():.3f}..{rgb.max():.3f} mean {rgb.mean():.3f} std {rgb.std():.3f}; "
               f"acc {ref['acc_fine'].min():.3f}..{ref['acc_fine'].max():.3f}; depth {ref['depth_fine'].min():.2f}.."

@@ -87,19 +87,39 @@ def sample_pdf(bins: torch.Tensor, weights: torch.Tensor, n_samples: int, u: Opt
     return bin_lo + t * (bin_hi - bin_lo)                           # rays.py:119
 
 
-def sample_pdf_terms(weights: torch.Tensor, n_samples: int):
-    """The intermediates of sample_pdf (rays.py:87-118) for conditioning analysis: (cdf_lo, cdf_hi, denom, below,
-    above) per importance sample, with `denom` AFTER the < 1e-5 -> 1 replacement (:114)."""
+def sample_pdf_cdf(weights: torch.Tensor) -> torch.Tensor:
+    """The cdf of rays.py:87-90 alone: weights [N, Ns-2] -> [N, Ns-1]."""
     weights = weights + 1e-5
     pdf = weights / torch.sum(weights, -1, keepdim=True)
-    cdf = torch.cat([torch.zeros_like(pdf[..., :1]), torch.cumsum(pdf, -1)], -1)
+    return torch.cat([torch.zeros_like(pdf[..., :1]), torch.cumsum(pdf, -1)], -1)
+
+
+def sample_pdf_diagnostics(bins: torch.Tensor, weights: torch.Tensor, n_samples: int) -> Dict[str, torch.Tensor]:
+    """Conditioning of sample_pdf (rays.py:103-119, det=True) per ray, the quantities include/nwe.h defines for the
+    kernel's `sample_cond` / `sample_amp` / `sample_switch` outputs:
+
+    min_denom  smallest cdf step BEFORE the `< 1e-5 -> 1` replacement (:113-114) over the samples interpolated between two
+               different cdf entries (the clamped end case below == above, :104-105, is left out);
+    amp        largest bin_width / denom (denom after the replacement): |d z / d cdf|, the first-order amplification of a
+               change in the coarse cdf.  A clamped sample (u = 1.0 against a cdf ending at or below 1) counts with the
+               last bin's step, because with the last cdf entry one ulp higher it is interpolated in that bin;
+    switch     smallest |denom - 1e-5| before the replacement: distance from the discontinuity of :114.
+    """
+    cdf = sample_pdf_cdf(weights)
     u = torch.linspace(0., 1., steps=n_samples).expand(list(cdf.shape[:-1]) + [n_samples]).contiguous()
     inds = torch.searchsorted(cdf, u, right=True)
     below, above = torch.clamp(inds - 1, min=0), torch.clamp(inds, max=cdf.shape[-1] - 1)
-    cdf_lo, cdf_hi = torch.gather(cdf, 1, below), torch.gather(cdf, 1, above)
-    denom = cdf_hi - cdf_lo
-    denom = torch.where(denom < 1e-5, torch.ones_like(denom), denom)
-    return cdf_lo, cdf_hi, denom, below, above
+    raw = torch.gather(cdf, 1, above) - torch.gather(cdf, 1, below)
+    used = torch.where(raw < 1e-5, torch.ones_like(raw), raw)
+    width = torch.gather(bins, 1, above) - torch.gather(bins, 1, below)
+    regular = above != below
+    big = torch.full_like(raw, 1.0)
+    last = cdf[:, -1:] - cdf[:, -2:-1]
+    last = torch.where(last < 1e-5, torch.ones_like(last), last)
+    amp_clamped = ((bins[:, -1:] - bins[:, -2:-1]) / last).expand_as(raw)
+    amp = torch.where(regular, width / used, amp_clamped)
+    return {"min_denom": torch.where(regular, raw, big).min(-1).values, "amp": amp.max(-1).values,
+            "switch": torch.where(regular, (raw - 1e-5).abs(), big).min(-1).values, "cdf": cdf}
 
 
 # --------------------------------------------------------------------------

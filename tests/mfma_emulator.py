@@ -94,8 +94,9 @@ def layer(st, n_tiles, segs, lower, three_pass=True):
     return np.concatenate(his, 0), np.concatenate(los, 0)
 
 
-def mlp_eval(stream_bytes, bias_tab, scale, pts, dirs, D, W, skip, three_pass=True):
-    """pts [n,3] (already divided by 10), dirs [n,3] -> raw [n,4] as the kernel would produce."""
+def mlp_eval(stream_bytes, bias_tab, scale, pts, dirs, D, W, skip, three_pass=True, folded=True):
+    """pts [n,3] (already divided by 10), dirs [n,3] -> raw [n,4] as the kernel would produce.  folded: the stream has no
+    feature-layer chunks (the packer multiplied _feature_linear into the view layer), the kernel's FOLD path."""
     st = Stream(stream_bytes, bias_tab, scale)
     G = encode(pts.T.astype(np.float32), 5, 4)
     GD = encode(dirs.T.astype(np.float32), 2, 2)
@@ -103,17 +104,17 @@ def mlp_eval(stream_bytes, bias_tab, scale, pts, dirs, D, W, skip, three_pass=Tr
     A = layer(st, NT, [G], 0.0, three_pass)
     npair = D // 2
     skip_pair = -1 if skip < 0 else skip // 2
-    sigma = None
     for pair in range(npair):
         last = pair == npair - 1
         segs = ([G] if pair == skip_pair else []) + [A]
         B = layer(st, NT, segs, 0.0, three_pass)
+        if folded and last:
+            break
         A = layer(st, NT, [B], -np.inf if last else 0.0, three_pass)
-        if last:
-            t = mma_tile(st, [B], three_pass)
-            assert np.array_equal(t[0], t[4]), "alpha tile rows 0 and 4 must be copies"
-            sigma = t[0]
-    Bv = layer(st, W // 64, [A, GD], 0.0, three_pass)
+    t = mma_tile(st, [B], three_pass)                      # _alpha_linear reads h = B in both formulations
+    assert np.array_equal(t[0], t[4]), "alpha tile rows 0 and 4 must be copies"
+    sigma = t[0]
+    Bv = layer(st, W // 64, [B if folded else A, GD], 0.0, three_pass)
     t = mma_tile(st, [Bv], three_pass)
     assert np.array_equal(t[0:3], t[4:7]), "rgb tile rows 4..6 must copy rows 0..2"
     assert st.pos == len(stream_bytes), (st.pos, len(stream_bytes))

@@ -111,3 +111,27 @@ def test_kernel_owns_m0(tmp_path):
                 assert re.fullmatch(r"s_mov_b32 m0, (s\d+|vcc_lo|vcc_hi)", ins), f"unexpected M0 use in the MFMA kernel: {ins!r}"
                 checked += 1
     assert checked > 0, "no LDS-DMA destination writes found: is this the right code object?"
+
+
+def test_outputs_struct_guard_and_integration_stub_layout():
+    """nwe_outputs carries its own size: a caller built against another version of include/nwe.h is refused instead of
+    having its pointers misread; and the struct printed in INTEGRATION.md has exactly the fields of the header."""
+    import ctypes as C
+    import re
+    lib = _lib.load()
+    header = open(os.path.join(ROOT, "include", "nwe.h")).read()
+    body = header[header.index("typedef struct nwe_outputs {"):header.index("} nwe_outputs;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    fields = re.findall(r"(?:float|uint32_t|uint64_t)\s*\*?\s*(\w+)\s*;", body)
+    assert fields == ["struct_bytes"] + list(_lib.OUTPUT_FIELDS), fields
+    stub = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    stub = stub[stub.index("class Outputs(C.Structure)"):stub.index("lib.nwe_last_error.restype")]
+    assert re.findall(r'"(\w+)"', stub) == fields
+    ctx = C.c_void_p()
+    assert lib.nwe_create(C.byref(ctx), -1) == 0
+    o = _lib.Outputs()
+    assert o.struct_bytes == C.sizeof(_lib.Outputs) == 8 * (1 + len(_lib.OUTPUT_FIELDS))
+    o.struct_bytes -= 8                                          # "an older header"
+    assert lib.nwe_render_rays(ctx, None, 0, 0, C.byref(o), None) == _lib.NWE_ERR_INVALID
+    assert b"struct_bytes" in lib.nwe_last_error(ctx)
+    lib.nwe_destroy(ctx)

@@ -130,21 +130,36 @@ def test_c1_frame_against_golden(r_c1, golden_dir, precision):
     assert np.array_equal(np.isnan(d_ref), np.isnan(d)) or cliff.any()    # acc == 0 -> NaN, like torch.max
 
 
+def sampler_first_order_bound(amp, dcdf):
+    """|dz| a change `dcdf` of the coarse cdf can cause at first order: z = bin_lo + (u - cdf_lo) / denom * width
+    (nerf/rays/rays.py:118-119) moves by width/denom * (|d cdf_lo| + t |d denom|) <= 3 * amp * dcdf (dcdf = the largest
+    change of a cdf entry, so a step changes by at most twice that); the inverse cdf is continuous across bin edges, so the
+    bound holds when a sample changes bins.  Measured: a third of it at most.  The 2e-6 floor leaves room for the fp32
+    rounding of z itself (depths up to 10)."""
+    return 3.0 * amp * dcdf + 2e-6
+
+
 @pytest.mark.parametrize("precision", ["f32", "f16x3"])
 @pytest.mark.parametrize("pose", ["hor0", "hor30"])
 def test_c3_subset_against_golden(r_c3, golden_dir, precision, pose):
-    """BASELINE config 3 (800x800, 64+128, 8x256, raw random networks) on the committed strided 4096-ray subset.
+    """BASELINE config 3 (800x800, 64+128, 8x256, raw random networks) on the committed strided 4096-ray subset: a closed
+    per-ray chain from the pose to the pixel.
 
-    With unrelated random coarse/fine networks the reference's importance sampling is ill conditioned on part of
-    the rays (an importance sample in a nearly empty coarse bin moves by up to ~1e-2 for a 1e-6 relative change of
-    the coarse weights, and the `denom < 1e-5` switch of nerf/rays/rays.py:114 is a discontinuity): perturbing the
-    reference's OWN coarse network output by 1e-6 relative moves ~1 % of its fine pixels by more than 1e-4
-    (tools/reference_instability.py).  So the comparison is staged:
-      T1  coarse pass, every ray, full tolerance;
-      T2  sample depths: nearly all equal, none further than a fraction of a coarse bin;
-      T3  fine pass ALONE, every ray, full tolerance: the oracle's fine pass evaluated on the kernel's depths,
-          and the kernel's fine pass evaluated on the reference's depths (debug hook);
-      T4  end to end: PSNR, median, and the share of rays above 1e-4 bounded.
+    With unrelated random coarse/fine networks the reference's importance sampling is ill conditioned on most rays: an
+    importance sample in a nearly empty coarse bin moves by bin_width/denom ~ 4e3 (up to 1.5e4) times a change of the coarse
+    cdf, and two fp32 evaluations of the coarse MLP (torch's sgemm blocking vs. any other order) differ by ~5e-7 in the
+    weights.  So a pixel-level comparison alone cannot say whether a deviating ray is a bug; the chain can:
+      T1   coarse pass, every ray: rgb / depth / acc at full tolerance and the coarse WEIGHTS (raw2outputs' 4th return,
+           model_utils.py:80, the sampler's input) within 2e-6 of the reference's;
+      T2a  the sampler on its OWN inputs, every ray: the reference's sample_pdf + sort (rays.py:74-121, handler.py:243) run on
+           the kernel's coarse weights gives the kernel's depths (<= 1e-6; the kernel adds the weights in torch.sum's order);
+      T2b  depths against the reference's, every ray: explained by the first-order bound 3 * amp * |d cdf| + 2e-6 with the
+           measured cdf difference, except rays with a sample next to the `denom < 1e-5` switch (rays.py:114), which are
+           counted;
+      T3   fine pass ALONE, every ray, full tolerance, both directions: the oracle's fine pass on the kernel's depths, and
+           the kernel's fine pass on the reference's depths (debug hook);
+      T4   end to end: every ray whose depths agree (<= 2e-5) is within 1e-4; every other ray was explained in T2b and is
+           counted; PSNR over all rays.
     """
     g = np.load(os.path.join(golden_dir, "e2e_c3_subset.npz"))
     fx, fy, cx, cy = O.intrinsics(800, 800)
@@ -153,23 +168,49 @@ def test_c3_subset_against_golden(r_c3, golden_dir, precision, pose):
     rays = rays_cpu.cuda()
     out = r_c3.render_rays(rays, precision=precision,
                            outputs=("rgb", "depth", "acc", "disp", "z_std", "rgb_coarse", "depth_coarse", "acc_coarse",
-                                    "z_fine", "sample_cond"))
+                                    "z_fine", "weights_coarse", "sample_cond", "sample_amp", "sample_switch"))
     tag = f"[{precision} {pose}]"
     # T1 ------------------------------------------------------------------------------------------
     cliff_c = np.abs(g[f"sigma_last_coarse_{pose}"]) < 1e-5
     errc = np.abs(out["rgb_coarse"].cpu().numpy() - g[f"rgb_coarse_{pose}"])
-    print(tag, "T1 coarse rgb max err", errc[~cliff_c].max(), "cliff rays", int(cliff_c.sum()))
+    w_k, w_ref = out["weights_coarse"].cpu(), torch.from_numpy(g[f"weights_coarse_{pose}"])
+    werr = (w_k - w_ref).abs().numpy()
+    werr[cliff_c, -1] = 0                       # the last weight of a cliff ray is the step function itself
+    print(tag, "T1 coarse rgb max err", errc[~cliff_c].max(), "weights max err", werr.max(), "cliff rays", int(cliff_c.sum()))
     assert errc[~cliff_c].max() <= RGB_TOL
     assert np.abs(out["depth_coarse"].cpu().numpy() - g[f"depth_coarse_{pose}"])[~cliff_c].max() / FAR <= 1e-4
     assert np.abs(out["acc_coarse"].cpu().numpy() - g[f"acc_coarse_{pose}"])[~cliff_c].max() <= 1e-4
-    # T2 ------------------------------------------------------------------------------------------
+    assert werr.max() <= 2e-6
+    # T2a -----------------------------------------------------------------------------------------
     z = out["z_fine"].cpu()
-    zerr = np.abs(z[:64].numpy() - g[f"z_fine_first64_{pose}"])
-    print(tag, "T2 depths: max err", zerr.max(), "share > 2e-5:", (zerr > 2e-5).mean())
-    assert (zerr > 2e-5).mean() < 0.02 and zerr.max() < 0.16
-    assert np.all(np.diff(z.numpy(), axis=1) >= -1e-6)                      # merge output is sorted
-    cond = out["sample_cond"].cpu().numpy()
-    assert np.median(np.abs(np.log(cond / g[f"min_denom_{pose}"]))) < 1e-3  # diagnostic agrees with the reference's denom
+    t = torch.linspace(0., 1., 64)
+    z_c = (rays_cpu[:, 6:7] * (1. - t) + rays_cpu[:, 7:8] * t)                                   # handler.py:216-218
+    z_mid = .5 * (z_c[..., 1:] + z_c[..., :-1])                                                 # :236
+    own = torch.sort(torch.cat([z_c, O.sample_pdf(z_mid, w_k[..., 1:-1], 128)], -1), -1).values  # :237-243 on the kernel's weights
+    e2a = (own - z).abs().max(-1).values.numpy()
+    print(tag, "T2a sampler on its own weights: max", e2a.max(), "rays > 1e-6:", int((e2a > 1e-6).sum()))
+    assert e2a.max() <= 1e-6
+    assert np.all(np.diff(z.numpy(), axis=1) >= 0)                                              # merge output is sorted
+    dg_own = O.sample_pdf_diagnostics(z_mid, w_k[..., 1:-1], 128)
+    for key, name, rel in (("min_denom", "sample_cond", 1e-5), ("amp", "sample_amp", 1e-3)):
+        a_, b_ = out[name].cpu().numpy(), dg_own[key].numpy()
+        assert np.max(np.abs(a_ - b_) / np.abs(b_)) <= rel, (name, np.max(np.abs(a_ - b_) / np.abs(b_)))
+    assert np.max(np.abs(out["sample_switch"].cpu().numpy() - dg_own["switch"].numpy())) <= 1e-9
+    # T2b -----------------------------------------------------------------------------------------
+    z_ref = torch.sort(torch.cat([z_c, torch.from_numpy(g[f"z_samples_{pose}"])], -1), -1).values
+    assert np.array_equal(z_ref[:64].numpy(), g[f"z_fine_first64_{pose}"])                      # the committed slice of the reference's own sort
+    dz = (z - z_ref).abs().max(-1).values.numpy()
+    dg_ref = O.sample_pdf_diagnostics(z_mid, w_ref[..., 1:-1], 128)
+    dcdf = (dg_own["cdf"] - dg_ref["cdf"]).abs().max(-1).values.numpy()
+    amp = np.maximum(dg_own["amp"].numpy(), dg_ref["amp"].numpy())
+    near_switch = np.minimum(dg_own["switch"].numpy(), dg_ref["switch"].numpy()) <= 2.0 * dcdf  # a denom can land on either side of 1e-5
+    bound = sampler_first_order_bound(amp, dcdf)
+    unexplained = (dz > bound) & ~near_switch
+    print(tag, f"T2b depths vs reference: {int((dz > 2e-5).sum())} rays differ by > 2e-5 (max {dz.max():.2e}); cdf difference median "
+          f"{np.median(dcdf):.1e} max {dcdf.max():.1e}; amplification median {np.median(amp):.0f} max {amp.max():.0f}; "
+          f"max dz/bound {np.max(dz / bound):.2f}; switch-adjacent rays {int(near_switch.sum())}; unexplained {int(unexplained.sum())}")
+    assert not unexplained.any()
+    assert near_switch.sum() <= 8
     # T3 ------------------------------------------------------------------------------------------
     sf = _t(_sd(1001, 8, 256))
     fo = O.fine_pass_given_depths(rays_cpu, z, sf, O.RenderConfig())
@@ -192,10 +233,16 @@ def test_c3_subset_against_golden(r_c3, golden_dir, precision, pose):
     cliff_g = np.abs(g[f"sigma_last_fine_{pose}"]) < 1e-5
     rgb = out["rgb"].cpu().numpy()
     err = np.abs(rgb - g[f"rgb_fine_{pose}"]).max(-1)
-    print(tag, "T4 end to end: psnr", psnr(rgb, g[f"rgb_fine_{pose}"]), "median", np.median(err), "share > 1e-4:",
-          (err > RGB_TOL).mean(), "max", err.max(), "cliff rays", int(cliff_g.sum()))
+    same_depths = (dz <= 2e-5) & ~cliff_g & ~cliff
+    moved = err > RGB_TOL
+    print(tag, f"T4 end to end: psnr {psnr(rgb, g[f'rgb_fine_{pose}']):.1f} dB, median {np.median(err):.1e}; rays with equal depths "
+          f"{int(same_depths.sum())}, their max err {err[same_depths].max():.2e}; rays above 1e-4: {int(moved.sum())} "
+          f"({moved.mean():.2%}), all with moved depths (min dz {dz[moved].min() if moved.any() else 0:.1e}), max {err.max():.1e}; "
+          f"cliff rays {int(cliff_g.sum())}")
+    assert err[same_depths].max() <= RGB_TOL                  # every ray sampled where the reference sampled it
+    assert not (moved & (dz <= 2e-5) & ~cliff_g & ~cliff).any()   # a ray above tolerance has moved depths, explained in T2b
     assert psnr(rgb, g[f"rgb_fine_{pose}"]) > 50
-    assert np.median(err) < 2e-6 and (err > RGB_TOL).mean() < 0.03 and err.max() < 2e-2
+    assert np.median(err) < 2e-6 and moved.mean() < 0.03 and err.max() < 5e-3
     assert cliff_g.sum() <= 8 and cliff_c.sum() <= 8
 
 
@@ -694,3 +741,79 @@ def test_further_mfma_shapes(D, Wn):
         assert np.abs(got["raw_coarse"].cpu().numpy() - ref["raw_coarse"].numpy()).max() <= 2e-5
         assert (got["rgb"] - f32["rgb"]).abs().cpu().numpy()[ok].max() <= RGB_TOL
     r.close()
+
+
+def _rays_from(d, near=0.1, far=10.0):
+    """[N,11] rays with origin 0 and the given (unnormalised) directions, the layout of nerf/rays/rays.py:26-30."""
+    d = torch.as_tensor(d, dtype=torch.float32)
+    n = d.shape[0]
+    return torch.cat([torch.zeros(n, 3), d, torch.full((n, 1), near), torch.full((n, 1), far), d / torch.norm(d, dim=-1, keepdim=True)], -1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision,mode", [("f32", -1), ("f16x3", 0), ("f16x3", 1)])
+def test_compositing_on_the_reference_edge_vectors(golden_dir, precision, mode):
+    """raw2outputs (nerf/models/model_utils.py:49-100) on the device, fed with the reference's own edge vectors through
+    nwe_debug_set_raw: sigma <= 0 everywhere (acc = 0, disp = NaN), saturated alpha, sigma_last = +1e-11 / -1e-11 / 1e-9
+    (the 1e10 last interval), all-zero sigma; then the same with the sigma noise of the training-mode forward
+    (:64-71).  Both kernels, both work decompositions of the MFMA kernel."""
+    r = nwe_amd.Renderer(0)
+    r.set_network(0, _sd(1000, 4, 128))                      # any network: its outputs are replaced
+    r.set_sampling(16, 0)
+    r.debug_set_decomposition(mode)
+    keys = ("rgb", "disp", "acc", "depth", "weights_coarse", "rgb_coarse")
+    g = np.load(os.path.join(golden_dir, "raw2outputs.npz"))
+    out = r.render_rays(_rays_from(g["d"]).cuda(), precision=precision, outputs=keys, debug_raw=(torch.from_numpy(g["raw"]), None))
+    for k, gk in (("rgb", "rgb"), ("acc", "acc"), ("depth", "depth"), ("weights_coarse", "weights")):
+        err = np.abs(out[k].cpu().numpy() - g[gk]).max()
+        print(precision, mode, k, err)
+        assert err <= 2e-6, (k, err)
+    d, dref = out["disp"].cpu().numpy(), g["disp"]
+    assert np.array_equal(np.isnan(d), np.isnan(dref)) and np.isnan(dref).sum() >= 2      # sigma <= 0 rows: 1 / max(1e-10, 0/0)
+    assert np.allclose(d[~np.isnan(dref)], dref[~np.isnan(dref)], rtol=1e-5)
+    assert int(out["flags"].item()) & (1 << 3)                                           # NWE_FLAG_DISP: the reference prints
+    # the step at the last interval: sigma_last = 1e-11 -> alpha 0.095..., -1e-11 -> 0, 1e-9 -> 1 - e^-10 (model_utils.py:54)
+    w_last = out["weights_coarse"].cpu().numpy()[:, -1]
+    assert w_last[4] == 0.0 and w_last[3] > 0.0 and w_last[5] > 0.0                    # sigma_last = -1e-11 / 1e-11 / 1e-9
+    t = np.load(os.path.join(golden_dir, "train_mode.npz"))
+    out = r.render_rays(_rays_from(t["r2o_d"]).cuda(), precision=precision, outputs=keys, debug_raw=(torch.from_numpy(t["r2o_raw"]), None),
+                        train={"noise_coarse": torch.from_numpy(t["r2o_noise"])})
+    for k, gk in (("rgb", "r2o_rgb"), ("acc", "r2o_acc"), ("depth", "r2o_depth"), ("weights_coarse", "r2o_weights")):
+        assert np.abs(out[k].cpu().numpy() - t[gk]).max() <= 2e-6, k
+    r.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision,mode", [("f32", -1), ("f16x3", 0), ("f16x3", 1)])
+def test_importance_sampling_on_the_reference_edge_vectors(r_c3, golden_dir, precision, mode):
+    """sample_pdf + the sorted merge (nerf/rays/rays.py:74-121, handler.py:243) on the device, fed with the reference's own
+    edge vectors through nwe_debug_set_coarse_weights: flat weights, a single spike, ALL-ZERO weights, random, mass at the
+    near end, mass in the last bin; u = 1.0 is the last of the 128 arguments of every row.  Then the det=False branch on
+    the reference's seeded uniform numbers."""
+    g = np.load(os.path.join(golden_dir, "sample_pdf.npz"))
+    n = g["weights"].shape[0]
+    rays = _rays_from(np.tile(np.array([[0.3, -0.2, 1.0]], np.float32), (n, 1)))
+    t = torch.linspace(0., 1., 64)
+    z_c = (0.1 * (1. - t) + 10.0 * t).expand(n, 64)
+    assert np.array_equal((.5 * (z_c[..., 1:] + z_c[..., :-1])).numpy(), g["bins"])              # the bins the reference was given
+    w = torch.zeros(n, 64)
+    w[:, 1:-1] = torch.from_numpy(g["weights"])
+    w[:, 0], w[:, -1] = 0.25, 0.5                                                               # the end weights are sliced off (handler.py:237)
+    r_c3.debug_set_decomposition(mode)
+    try:
+        out = r_c3.render_rays(rays.cuda(), precision=precision, outputs=("z_fine", "z_std", "sample_cond", "sample_amp", "rgb"),
+                               debug_coarse_weights=w)
+        want = torch.sort(torch.cat([z_c, torch.from_numpy(g["samples"])], -1), -1).values
+        err = (out["z_fine"].cpu() - want).abs().max().item()
+        print(precision, mode, "z_fine max err", err)
+        assert err <= 1e-6
+        assert np.abs(out["z_std"].cpu().numpy() - g["samples"].std(-1)).max() <= 1e-5
+        assert torch.isfinite(out["rgb"]).all()
+        tm = np.load(os.path.join(golden_dir, "train_mode.npz"))
+        w[:, 1:-1] = torch.from_numpy(tm["pdf_weights"])
+        out = r_c3.render_rays(rays.cuda(), precision=precision, outputs=("z_fine",), debug_coarse_weights=w,
+                               train={"u": torch.from_numpy(tm["pdf_u"])})
+        want = torch.sort(torch.cat([z_c, torch.from_numpy(tm["pdf_samples"])], -1), -1).values
+        assert (out["z_fine"].cpu() - want).abs().max().item() <= 1e-6
+    finally:
+        r_c3.debug_set_decomposition(-1)

@@ -10,25 +10,43 @@ from oracle import nerf_oracle as O
 from tests import mfma_emulator as E
 
 
-@pytest.mark.parametrize("D,W,seed,n_tiles,n_chunks", [(8, 256, 1001, 2368, 78), (4, 128, 1000, 352, 24)])
-def test_stream_replay_matches_oracle(D, W, seed, n_tiles, n_chunks):
+@pytest.mark.parametrize("D,W,seed,folded,n_tiles,n_chunks", [
+    (8, 256, 1001, True, 2112, 70), (8, 256, 1001, False, 2368, 78), (4, 128, 1000, True, 288, 20), (4, 128, 1000, False, 352, 24),
+    (6, 256, 7, True, 1600, 54), (6, 128, 8, True, 448, 28), (8, 128, 9, True, 576, 36), (4, 256, 10, True, 1024, 38)])
+def test_stream_replay_matches_oracle(D, W, seed, folded, n_tiles, n_chunks):
     sd = nwe_amd.synthetic.make_state_dict(seed, D, W)
     r = nwe_amd.Renderer(host_only=True)
+    r.debug_set_fold(folded)
     shape = r.set_network(0, sd)
     stream, bias, scale = r.packed_stream(0), r.packed_bias(0), r.packed_scale(0)
     assert stream.size == n_tiles * 1024 and bias.shape == (n_chunks, 32)
-    wmax = max(np.abs(v).max() for k, v in sd.items() if k.endswith("weight"))
+    packed = {k: v for k, v in sd.items() if k.endswith("weight")}
+    if folded:   # _feature_linear is multiplied into the view layer (nerf_model.py:64-70): the product is what gets packed
+        wv = packed.pop("_views_linears.0.weight").astype(np.float64)
+        wf = packed.pop("_feature_linear.weight").astype(np.float64)
+        packed["folded"] = np.concatenate([wv[:, :W] @ wf, wv[:, W:]], 1)
+    wmax = max(np.abs(v).max() for v in packed.values())
     assert 2.0 ** 13 <= wmax * scale <= 2.0 ** 14 and np.log2(scale) == round(np.log2(scale))   # power of two, fp16 headroom
     g = torch.Generator().manual_seed(3)
     pts = (torch.rand(32, 3, generator=g) * 2 - 1) * torch.tensor([8.0, 3.0, 1.0])
     dirs = torch.nn.functional.normalize(torch.randn(32, 3, generator=g), dim=-1)
     x = torch.cat([O.embed(pts, 10, 10), O.embed(dirs, 4, 1)], -1)
     ref = O.mlp_forward({k: torch.from_numpy(v) for k, v in sd.items()}, x).numpy()
-    got = E.mlp_eval(stream, bias, scale, (pts / 10).numpy(), dirs.numpy(), D, W, shape[4], three_pass=True)
+    got = E.mlp_eval(stream, bias, scale, (pts / 10).numpy(), dirs.numpy(), D, W, shape[4], three_pass=True, folded=folded)
     assert np.abs(got - ref).max() < 2e-5, np.abs(got - ref).max()
     # single-pass fp16 is visibly worse but still close: the split is what buys fp32-grade results
-    got1 = E.mlp_eval(stream, bias, scale, (pts / 10).numpy(), dirs.numpy(), D, W, shape[4], three_pass=False)
+    got1 = E.mlp_eval(stream, bias, scale, (pts / 10).numpy(), dirs.numpy(), D, W, shape[4], three_pass=False, folded=folded)
     assert 2e-5 < np.abs(got1 - ref).max() < 5e-2
+
+
+def test_unfolded_stream_only_for_the_baseline_shapes():
+    r = nwe_amd.Renderer(host_only=True)
+    r.debug_set_fold(False)
+    r.set_network(0, nwe_amd.synthetic.make_state_dict(5, 6, 256))
+    assert r.packed_stream(0).size == 0
+    r.debug_set_fold(True)
+    r.set_network(0, nwe_amd.synthetic.make_state_dict(5, 6, 256))
+    assert r.packed_stream(0).size == 1600 * 1024
 
 
 def test_unsupported_shape_has_no_stream():
