@@ -10,6 +10,13 @@ the tiles to rank 0, so per-GPU work is fixed (640 000 rays = 122.88 M ray-sampl
 Inputs (weights, tables) are resident in HBM before the timed region; the only host->device traffic in a step
 is the 64-byte poses.  Rank 0 prints ONE JSON line.
 
+For N > 1 the line also carries, measured AFTER the timed region of the headline number:
+`strong`  = BASELINE config 4: ONE 800x800 frame sharded N ways (80 000 rays per rank at N = 8) + gather, ms per frame
+            (max over ranks) and the per-rank kernel time, i.e. the latency case where the last round of workgroups
+            dominates - weak scaling cannot show a loss there by construction;
+`in_process` = the same single frame through nwe_render_tiled from rank 0 alone (N contexts in one process,
+            hipMemcpyPeerAsync into the frame): the path a GUI thread uses.  Best effort: an error is reported, not raised.
+
 `roofline` prices the render kernel (the only kernel of the path) against the dense fp16 MFMA peak with the
 ALGORITHMIC FLOPs of the reference formulation (2 x GEMM MACs, SURVEY.md §8d: 1 186 816 FLOP per MLP
 evaluation, 64 coarse + 192 fine evaluations per ray); its duration comes from HIP events recorded by the
@@ -33,12 +40,11 @@ if ROOT not in sys.path:
 
 H = W = 800
 NS, NI = 64, 128
+STRONG_STEPS = 5
 LIBRARY_GEMM_F16_TFLOPS = 1330.0   # measured on this pool, tools/gemm_reference.py
 POWER_CAPPED_F16_TFLOPS = 1650.0   # measured on this pool, see profiles/r01_ubench_mfma_power.txt
 PEAK_F16_TFLOPS = 2500.0   # dense fp16/bf16 MFMA peak, MI355X_MICROARCH.md
-# HBM-side bytes of one C3-frame launch from rocprofv3 PMC passes (profiles/r01_pmc_traffic.txt): 2 x FETCH_SIZE (gfx950
-# reports half of a 16-B-per-lane stream) + WRITE_SIZE; L2 misses of the 3.1 TB weight stream, not a bound (21 GB/s).
-TRAFFIC_BYTES_C3_LAUNCH = (2 * 5.229e6 + 3.25e4) * 1024   # FETCH_SIZE x 2 (gfx950) + WRITE_SIZE, in KB; final round-1 kernel, profiles/r01_pmc_traffic.txt
+TRAFFIC_PROFILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_pmc_traffic.json")
 CPU_SAMPLE_RAYS = 8192     # one reference chunk (inference.chunk = 1024*8): ~10 s of CPU work on 8-16 cores
 
 
@@ -50,11 +56,49 @@ def sweep_pose(k: int, n: int) -> np.ndarray:
     return get_camera_poses_from_list_of_coordinates(init, [COORD(yaw=-hor)])[0].numpy()
 
 
+def kernel_source_sha() -> str:
+    """sha256 over the kernel sources: ties a committed counter profile to the build it was taken on."""
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "nerf-workspaces-explorer_amd", "csrc")
+    for name in sorted(os.listdir(csrc)):
+        if name.endswith((".hip", ".h")):
+            h.update(open(os.path.join(csrc, name), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def profiled_traffic():
+    """(bytes per C3 launch, note): HBM-side bytes from separate rocprofv3 --pmc passes over this same command
+    (tools/pmc_traffic.sh -> profiles/r02_pmc_traffic.json), used only when that profile was taken on the kernel sources
+    in the tree; otherwise (None, why) - counters cannot be read inside this run."""
+    try:
+        prof = json.load(open(TRAFFIC_PROFILE))
+    except (OSError, ValueError):
+        return None, "no counter profile committed for this build"
+    if prof.get("kernel_source_sha") != kernel_source_sha():
+        return None, f"profiles/r02_pmc_traffic.json was taken on kernel sources {prof.get('kernel_source_sha')}, not the ones in the tree"
+    return float(prof["hbm_bytes_per_launch"]), prof.get("note", "")
+
+
+def cpu_model() -> str:
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(sd_c, sd_f, pose):
     """The oracle on one 8192-ray chunk taken from the middle of the frame, all host threads."""
     from oracle import nerf_oracle as O
     # the GPU box gives one GPU's job a 16-core share; more threads than that only oversubscribe the small GEMMs
-    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    torch.set_num_threads(min(16, avail))
     fx, fy, cx, cy = O.intrinsics(H, W)
     rays = O.create_rays(torch.from_numpy(pose)[None], H, W, fx, fy, cx, cy, 0.1, 10.0)[0]
     start = (H // 2) * W
@@ -62,9 +106,9 @@ def cpu_baseline(sd_c, sd_f, pose):
     t = lambda sd: {k: torch.from_numpy(v) for k, v in sd.items()}
     cfg = O.RenderConfig(n_samples=NS, n_importance=NI)
     t0 = time.perf_counter()
-    ref = O.render_rays(rays, t(sd_c), t(sd_f), cfg, keep=("rgb_fine", "raw_fine"))
+    ref = O.render_rays(rays, t(sd_c), t(sd_f), cfg, keep=("rgb_fine", "raw_fine", "z_fine"))
     dt = time.perf_counter() - t0
-    return rays, ref, dt, start
+    return rays, ref, dt, start, torch.get_num_threads()
 
 
 def main() -> None:
@@ -134,12 +178,41 @@ def main() -> None:
     samples_per_step = rays_per_step * (NS + NI)
     evals_per_ray = NS + (NS + NI)
     value = samples_per_step * args.steps / elapsed
+    k_ms = float(np.mean(kernel_ms))
+
+    # ---- after the headline measurement: the single-frame (strong scaling) case, N > 1 only ---------------------------------
+    strong = None
+    if world > 1:
+        one = poses[:1]
+        skm = []
+        for _ in range(2):
+            tsr.render_frames(one, H, W)
+        fence()
+        t1 = time.perf_counter()
+        for _ in range(STRONG_STEPS):
+            tsr.render_frames(one, H, W)
+            skm.append(h.renderer.last_kernel_ms())
+        fence()
+        st = torch.tensor([time.perf_counter() - t1, float(np.mean(skm))], dtype=torch.float64, device="cuda")
+        dist.all_reduce(st, op=dist.ReduceOp.MAX)
+        ms_frame = float(st[0].item()) / STRONG_STEPS * 1e3
+        strong = {"workload": f"C4: ONE 800x800 frame as {world} row tiles ({H // world * W} rays per rank) + RCCL gather",
+                  "ms_per_frame": ms_frame, "frames_per_s": 1e3 / ms_frame, "ray_samples_per_s": H * W * (NS + NI) / ms_frame * 1e3,
+                  "kernel_ms_slowest_rank": float(st[1].item()), "steps": STRONG_STEPS,
+                  "speedup_vs_this_run_single_gpu_frame": k_ms / ms_frame, "note": "single_gpu_frame = this run's kernel time for "
+                  "640 000 rays on one rank (the weak-scaling launch); ideal speedup = n_gpus"}
 
     if rank == 0:
-        flops_per_launch = (H * W * frames_per_step // world) * (NS * h.renderer.flops_per_eval(0) + (NS + NI) * h.renderer.flops_per_eval(1))
-        k_ms = float(np.mean(kernel_ms))
+        r0 = h.renderer
+        flops_per_launch = (H * W * frames_per_step // world) * (NS * r0.flops_per_eval(0) + (NS + NI) * r0.flops_per_eval(1))
         achieved = flops_per_launch / (k_ms * 1e-3) / 1e12
         passes = {"f16x3": 3, "f16x1": 1, "f32": 1}[args.precision]
+        # executed MFMA FLOPs: one v_mfma_f32_32x32x16_f16 (32 768 FLOP, 32 rays) per (hi, lo) tile pair of the packed stream
+        # and pass, i.e. padding (63 -> 64, 27 -> 32, head rows) and the folded feature layer included as executed
+        mfma_per_eval = [r0.packed_stream(w).size // 2048 for w in (0, 1)]
+        executed = (H * W * frames_per_step // world) / 32 * (NS * mfma_per_eval[0] + (NS + NI) * mfma_per_eval[1]) * passes * 32768
+        exec_tflops = executed / (k_ms * 1e-3) / 1e12 if args.precision != "f32" else None
+        traffic, traffic_note = profiled_traffic() if (world == 1 and args.precision == "f16x3" and not args.unfolded) else (None, "not profiled for this mode")
         line = {
             "metric": "ray-samples/sec (800x800, 192 samples, 8x256 MLP)", "value": value, "unit": "ray-samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
@@ -155,38 +228,78 @@ def main() -> None:
             "mlp_evals_per_s": rays_per_step * evals_per_ray * args.steps / elapsed,
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_F16_TFLOPS,
-                         "traffic": TRAFFIC_BYTES_C3_LAUNCH if (world == 1 and args.precision == "f16x3") else None,
-                         "traffic_note": "HBM-side bytes per launch from separate rocprofv3 --pmc passes (profiles/r01_pmc_traffic.txt), "
-                                         "not measured in this run; algorithmic 1.76e7 B",
-                         "kernel": "render_mfma_kernel<256,8,4>" if args.precision != "f32" else "render_f32_kernel",
+                         "traffic": traffic, "traffic_note": traffic_note + "; algorithmic 1.76e7 B per launch (poses in, weights once, rgb/depth/acc out)",
+                         "kernel": ("render_mfma_kernel<256,8,4,%s>" % ("unfolded" if args.unfolded else "folded")) if args.precision != "f32" else "render_f32_kernel",
                          "kernel_ms": k_ms, "algorithmic_flops_per_launch": flops_per_launch,
-                         "executed_mfma_passes": passes, "frac_executed": achieved * passes / PEAK_F16_TFLOPS,
+                         "executed_mfma_passes": passes, "mfma_per_eval_and_pass": mfma_per_eval,
+                         "executed_mfma_tflops": exec_tflops,
+                         "frac_executed": None if exec_tflops is None else exec_tflops / PEAK_F16_TFLOPS,
                          # what a bare dependent chain of this MFMA sustains on RANDOM operands under the socket power cap
                          # (tools/ubench/mfma_power.hip, profiles/r01_ubench_mfma_power.txt: 1.57-1.75 GHz at ~1300 W)
                          "power_capped_mfma_peak": POWER_CAPPED_F16_TFLOPS,
-                         "frac_executed_of_power_capped_peak": achieved * passes / POWER_CAPPED_F16_TFLOPS,
+                         "frac_executed_of_power_capped_peak": None if exec_tflops is None else exec_tflops / POWER_CAPPED_F16_TFLOPS,
                          # torch.matmul (hipBLASLt) fp16 8192^3 on random operands, same pool (profiles/r01_gemm_reference.txt)
                          "library_gemm_f16_sustained": LIBRARY_GEMM_F16_TFLOPS},
         }
+        if strong is not None:
+            line["strong"] = strong
+            line["in_process"] = in_process_frame(args, sd_c, sd_f, poses[0], world, torch.cuda.device_count())
         if world == 1 and not args.no_cpu_baseline:
-            rays, ref, dt, start = cpu_baseline(sd_c, sd_f, poses[0])
+            rays, ref, dt, start, threads = cpu_baseline(sd_c, sd_f, poses[0])
             cpu_value = CPU_SAMPLE_RAYS * (NS + NI) / dt
-            line["cpu_baseline"] = {"value": cpu_value, "unit": "ray-samples/s", "cores": torch.get_num_threads(), "kind": "port",
+            line["cpu_baseline"] = {"value": cpu_value, "unit": "ray-samples/s", "cores": threads, "kind": "port",
+                                    "cpu_model": cpu_model(), "logical_cpus_visible": os.cpu_count(),
                                     "sample": f"{CPU_SAMPLE_RAYS} rays (rows {start // W}..) of the same frame = one reference chunk, "
-                                              f"oracle/nerf_oracle.py on torch CPU fp32, {dt:.1f} s",
+                                              f"oracle/nerf_oracle.py on torch CPU fp32, {threads} threads, {dt:.1f} s",
                                     "frame_s_extrapolated": H * W * (NS + NI) / cpu_value}
             # image quality of the timed frame against the oracle on the same rays (metric: "PSNR vs ref")
             got = frame["rgb"][0].reshape(-1, 3)[start:start + CPU_SAMPLE_RAYS].cpu().numpy()
             mse = float(np.mean((got.astype(np.float64) - ref["rgb_fine"].numpy().astype(np.float64)) ** 2))
             err = np.abs(got - ref["rgb_fine"].numpy()).max(-1)
             line["psnr_vs_oracle_db"] = 99.0 if mse == 0 else -10.0 * np.log10(mse)
-            line["rgb_abs_err_vs_oracle"] = {"median": float(np.median(err)), "p99": float(np.quantile(err, 0.99)),
-                                             "share_above_1e-4": float((err > 1e-4).mean()),
-                                             "note": "random coarse/fine nets: ~1-2% of rays sit on reference sampling "
-                                                     "instabilities (DESIGN.md); fine pass on equal depths agrees to 4e-7"}
+            # attribution, ray by ray (tests/test_gpu_parity.py::test_c3_subset_against_golden does this on the golden subset):
+            # re-render the sample's rows with the sample depths as an output and compare them with the oracle's
+            rows = (start // W, (start + CPU_SAMPLE_RAYS + W - 1) // W)
+            chk = h.render_batch(poses[:1], H, W, rows=rows, outputs=("rgb", "z_fine"))
+            assert torch.equal(chk["rgb"].reshape(-1, 3)[:CPU_SAMPLE_RAYS], frame["rgb"][0].reshape(-1, 3)[start:start + CPU_SAMPLE_RAYS])
+            dz = (chk["z_fine"].reshape(-1, NS + NI)[:CPU_SAMPLE_RAYS].cpu() - ref["z_fine"]).abs().max(-1).values.numpy()
+            cliff = ref["raw_fine"][:, -1, 3].abs().numpy() < 1e-5
+            same = (dz <= 2e-5) & ~cliff
+            line["rgb_abs_err_vs_oracle"] = {
+                "median": float(np.median(err)), "p99": float(np.quantile(err, 0.99)), "share_above_1e-4": float((err > 1e-4).mean()),
+                "rays": CPU_SAMPLE_RAYS, "rays_with_the_oracles_sample_depths": int(same.sum()),
+                "max_err_on_those": float(err[same].max()), "above_1e-4_on_those": int((err[same] > 1e-4).sum()),
+                "above_1e-4_with_moved_depths": int(((err > 1e-4) & ~same).sum()), "cliff_rays": int(cliff.sum()),
+                "note": "random unrelated coarse/fine nets: the reference's inverse-CDF sampling amplifies the ~5e-7 difference "
+                        "between two fp32 evaluations of the coarse MLP by up to 1e4 in depth (DESIGN.md section 6); every ray "
+                        "above 1e-4 is one whose sample depths moved, every ray sampled where the oracle sampled it is within 1e-4"}
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def in_process_frame(args, sd_c, sd_f, pose, n, n_visible):
+    """One C3 frame through nwe_render_tiled from this process alone: n contexts on devices 0..n-1, tiles copied into the
+    frame with hipMemcpyPeerAsync.  The other ranks are idle (behind the barrier) while this runs."""
+    try:
+        import nwe_amd
+        if n_visible < n:
+            return {"skipped": f"{n_visible} devices visible to this process, {n} needed"}
+        hh = nwe_amd.NeRFReplicaInferenceHandler("office_tokyo", "synthetic", precision=args.precision, devices=list(range(n)))
+        hh.set_sampling(NS, NI)
+        hh.initialize_models(state_dicts=(sd_c, sd_f))
+        for _ in range(2):
+            hh.render_batch(pose[None], H, W)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(STRONG_STEPS):
+            out = hh.render_batch(pose[None], H, W)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / STRONG_STEPS * 1e3
+        return {"workload": f"ONE 800x800 frame as {n} row tiles on devices 0..{n - 1} from one process (nwe_render_tiled)",
+                "ms_per_frame": ms, "tile_kernel_ms": hh.renderer.tile_kernel_ms(), "flags": int(out["flags"].item())}
+    except Exception as exc:   # noqa: BLE001 - a diagnostic leg must not take the headline number down with it
+        return {"error": f"{type(exc).__name__}: {exc}"}
 
 
 if __name__ == "__main__":

@@ -120,6 +120,20 @@ int nwe_render(nwe_ctx *ctx, const float *c2w, int n_poses, int H, int W, float 
                float near, float far, int row_begin, int row_end, int precision, const nwe_outputs *out,
                void *stream);
 
+/* One process, several contexts: every context renders one contiguous row tile of every pose - context i the rows
+ * dist.shard_rows(H, n_ctx)[i], the first H % n_ctx tiles one row longer - on a stream of its own, and copies it into the
+ * caller's row-major frames on contexts[0]'s device (hipMemcpyPeerAsync: xGMI between devices, a plain device copy when the
+ * contexts share a device; "several tiles on one device" and "one tile per device" are the same code).  The caller's
+ * stream (on contexts[0]'s device) continues when all tiles have landed.  Every context must have its networks and
+ * sampling tables set, identically.  rgb_dev [n_poses,H,W,3], depth_dev / acc_dev [n_poses,H,W], flags_dev [1]; each may be
+ * NULL.  Errors are reported on contexts[0].
+ * Why it exists: the reference renders from its GUI thread (application/app.py:336 -> application/workspace.py:66 ->
+ * render_coordinates), which cannot be one rank of a torchrun job; this is the multi-GPU path of that call.  (One process
+ * per GPU with an RCCL gather is nwe_amd/dist.py.) */
+int nwe_render_tiled(nwe_ctx *const *contexts, int n_ctx, const float *c2w, int n_poses, int H, int W, float fx, float fy,
+                     float cx, float cy, float near, float far, int precision, float *rgb_dev, float *depth_dev,
+                     float *acc_dev, uint32_t *flags_dev, void *stream);
+
 /* Generate the rays of nwe_render() without rendering them: DEVICE rays_out [n_poses*(row_end-row_begin)*W, 11]
  * fp32 = [o(3) d(3) near far viewdir(3)], bit-identical to the reference's CPU result.
  * Replaces: create_rays (nerf/rays/rays.py:6-32). */

@@ -10,10 +10,10 @@ from .camera_poses import get_camera_poses_from_list_of_coordinates   # noqa: F4
 from .config import Config, ConfigError                    # noqa: F401
 from .data_descriptors import COORD, HW, XYZ               # noqa: F401
 from .handler import NeRFReplicaInferenceHandler, load_checkpoint, pinhole_intrinsics   # noqa: F401
-from .renderer import Renderer                             # noqa: F401
+from .renderer import Renderer, TiledRenderer              # noqa: F401
 from .workspace import (OFFICES, OfficeBelgradeWorkspace, OfficeGeneveWorkspace, OfficeNewYorkWorkspace,   # noqa: F401
                         OfficeTokyoWorkspace, Workspace, click_to_coordinates)
 
-__all__ = ["NeRFReplicaInferenceHandler", "Renderer", "COORD", "HW", "XYZ", "Config", "ConfigError",
+__all__ = ["NeRFReplicaInferenceHandler", "Renderer", "TiledRenderer", "COORD", "HW", "XYZ", "Config", "ConfigError",
            "get_camera_poses_from_list_of_coordinates", "load_checkpoint", "pinhole_intrinsics", "synthetic", "Workspace", "OFFICES",
            "click_to_coordinates", "OfficeTokyoWorkspace", "OfficeNewYorkWorkspace", "OfficeGeneveWorkspace", "OfficeBelgradeWorkspace"]

@@ -17,7 +17,7 @@ OUTPUT_FIELDS = ("rgb", "depth", "acc", "disp", "z_std", "rgb_coarse", "depth_co
                  "raw_coarse", "raw_fine", "z_fine", "weights_coarse", "sample_cond", "sample_amp", "sample_switch", "flags")
 
 # every symbol include/nwe.h declares (tests/test_abi.py checks the library exports all of them)
-SYMBOLS = ("nwe_create", "nwe_destroy", "nwe_last_error", "nwe_set_network", "nwe_set_sampling", "nwe_render",
+SYMBOLS = ("nwe_create", "nwe_destroy", "nwe_last_error", "nwe_set_network", "nwe_set_sampling", "nwe_render", "nwe_render_tiled",
            "nwe_create_rays", "nwe_render_rays", "nwe_to8b", "nwe_flops_per_eval", "nwe_last_kernel_ms", "nwe_packed_bytes",
            "nwe_packed_copy", "nwe_packed_bias_count", "nwe_packed_bias_copy", "nwe_packed_scale",
            "nwe_debug_set_fine_depths", "nwe_debug_set_raw", "nwe_debug_set_coarse_weights", "nwe_debug_set_fold", "nwe_set_train_tables", "nwe_set_white_background", "nwe_debug_set_decomposition", "nwe_debug_set_stamps", "nwe_selftest")
@@ -53,6 +53,7 @@ def load() -> C.CDLL:
         "nwe_set_network": (I, [P, I, I, I, I, I, I, C.POINTER(P), C.POINTER(P)]),
         "nwe_set_sampling": (I, [P, P, P, I, P, I]),
         "nwe_render": (I, [P, P, I, I, I, F, F, F, F, F, F, I, I, I, C.POINTER(Outputs), P]),
+        "nwe_render_tiled": (I, [C.POINTER(P), I, P, I, I, I, F, F, F, F, F, F, I, P, P, P, P, P]),
         "nwe_create_rays": (I, [P, P, I, I, I, F, F, F, F, F, F, I, I, P, P]),
         "nwe_render_rays": (I, [P, P, I64, I, C.POINTER(Outputs), P]),
         "nwe_to8b": (I, [P, P, P, I64, P]),

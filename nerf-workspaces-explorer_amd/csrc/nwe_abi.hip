@@ -54,6 +54,16 @@ struct nwe_ctx {
     const float* dbg_z_fine = nullptr;
     const float *dbg_raw_c = nullptr, *dbg_raw_f = nullptr, *dbg_w = nullptr;   // nwe_debug_set_raw / _coarse_weights, one call
     int fold = 1;             // nwe_debug_set_fold: read by nwe_set_network
+    // nwe_render_tiled: this context's row tile (rgb | depth | acc slabs + its flag word), its own stream, and the event
+    // that says "tile rendered and copied into the frame"
+    float* tile_buf = nullptr;
+    size_t tile_cap = 0;       // floats
+    uint32_t* tile_flags = nullptr;
+    hipStream_t tile_stream = nullptr;
+    hipEvent_t tile_done = nullptr;
+    hipEvent_t frame_ready = nullptr;   // contexts[0] only: recorded on the caller's stream when the call starts
+    uint32_t* flag_parts = nullptr;     // contexts[0] only: one flag word per tile, on its device
+    int flag_parts_cap = 0;
     int white_bkgd = 0;
     int decomposition = -1;   // nwe_debug_set_decomposition
     unsigned long long* stamps = nullptr;   // nwe_debug_set_stamps
@@ -244,6 +254,12 @@ __global__ void to8b_kernel(const float* __restrict__ x, uint8_t* __restrict__ y
     }
 }
 
+__global__ void or_flags_kernel(const uint32_t* __restrict__ parts, int n, uint32_t* __restrict__ out) {
+    uint32_t f = 0;
+    for (int i = 0; i < n; ++i) f |= parts[i];
+    if (f) atomicOr(out, f);
+}
+
 __global__ void create_rays_kernel(RenderArgs a, float* __restrict__ out) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.n_rays) return;
@@ -348,6 +364,13 @@ void nwe_destroy(nwe_ctx* c) {
         (void)hipSetDevice(c->device);
         for (NetState& n : c->net) { if (n.d_blob) (void)hipFree(n.d_blob); if (n.d_stream) (void)hipFree(n.d_stream); if (n.d_bias) (void)hipFree(n.d_bias); }
         if (c->d_t) (void)hipFree(c->d_t);
+        if (c->tile_stream) (void)hipStreamSynchronize(c->tile_stream);
+        if (c->tile_buf) (void)hipFree(c->tile_buf);
+        if (c->tile_flags) (void)hipFree(c->tile_flags);
+        if (c->flag_parts) (void)hipFree(c->flag_parts);
+        if (c->tile_done) (void)hipEventDestroy(c->tile_done);
+        if (c->frame_ready) (void)hipEventDestroy(c->frame_ready);
+        if (c->tile_stream) (void)hipStreamDestroy(c->tile_stream);
         for (nwe_ctx::Slot& sl : c->slots) {
             if (sl.used) (void)hipEventSynchronize(sl.ev1);
             if (sl.d_poses) (void)hipFree(sl.d_poses);
@@ -448,6 +471,94 @@ int nwe_render(nwe_ctx* c, const float* c2w, int n_poses, int H, int W, float fx
     return launch(c, *slot, a, precision, stream);
 }
 
+int nwe_render_tiled(nwe_ctx* const* ctxs, int n_ctx, const float* c2w, int n_poses, int H, int W, float fx, float fy, float cx,
+                     float cy, float near, float far, int precision, float* rgb_dev, float* depth_dev, float* acc_dev,
+                     uint32_t* flags_dev, void* stream_) {
+    if (!ctxs || n_ctx < 1 || !ctxs[0]) return fail(nullptr, NWE_ERR_INVALID, "nwe_render_tiled: no contexts");
+    nwe_ctx* c0 = ctxs[0];
+    for (int i = 0; i < n_ctx; ++i)
+        if (!ctxs[i] || ctxs[i]->host_only) return fail(c0, NWE_ERR_INVALID, "nwe_render_tiled: null or host-only context");
+    if (!c2w || n_poses < 1 || H < 1 || W < 1) return fail(c0, NWE_ERR_INVALID, "bad pose / image");
+    hipStream_t stream0 = (hipStream_t)stream_;
+    // the caller's buffers may still be in use by earlier work on its stream: every tile stream starts behind this point
+    HIPCHK(c0, hipSetDevice(c0->device));
+    if (!c0->frame_ready) HIPCHK(c0, hipEventCreateWithFlags(&c0->frame_ready, hipEventDisableTiming));
+    if (c0->flag_parts_cap < n_ctx) {
+        if (c0->flag_parts) { (void)hipFree(c0->flag_parts); c0->flag_parts = nullptr; c0->flag_parts_cap = 0; }
+        HIPCHK(c0, hipMalloc(&c0->flag_parts, (size_t)n_ctx * sizeof(uint32_t)));
+        c0->flag_parts_cap = n_ctx;
+    }
+    HIPCHK(c0, hipMemsetAsync(c0->flag_parts, 0, (size_t)n_ctx * sizeof(uint32_t), stream0));
+    HIPCHK(c0, hipEventRecord(c0->frame_ready, stream0));
+    const int base = H / n_ctx, extra = H % n_ctx;      // dist.shard_rows: the first H % n tiles get one more row
+    int r0 = 0, rc_all = NWE_OK;
+    for (int i = 0; i < n_ctx && rc_all == NWE_OK; ++i) {
+        nwe_ctx* c = ctxs[i];
+        const int rows = base + (i < extra ? 1 : 0), r1 = r0 + rows;
+        const size_t px = (size_t)rows * W;             // pixels of one pose's tile
+        auto step = [&]() -> int {
+            HIPCHK(c, hipSetDevice(c->device));
+            if (!c->tile_stream) {
+                HIPCHK(c, hipStreamCreateWithFlags(&c->tile_stream, hipStreamNonBlocking));
+                HIPCHK(c, hipEventCreateWithFlags(&c->tile_done, hipEventDisableTiming));
+                HIPCHK(c, hipMalloc(&c->tile_flags, sizeof(uint32_t)));
+                if (c->device != c0->device) {
+                    int can = 0;
+                    (void)hipDeviceCanAccessPeer(&can, c->device, c0->device);
+                    // direct xGMI copies into the frame; without peer access the runtime stages the copy through the host
+                    if (can && hipDeviceEnablePeerAccess(c0->device, 0) != hipSuccess) (void)hipGetLastError();   // "already enabled" included
+                }
+            }
+            const size_t need = (size_t)n_poses * px * 5;
+            if (c->tile_cap < need) {
+                HIPCHK(c, hipStreamSynchronize(c->tile_stream));
+                if (c->tile_buf) { (void)hipFree(c->tile_buf); c->tile_buf = nullptr; c->tile_cap = 0; }
+                HIPCHK(c, hipMalloc(&c->tile_buf, need * sizeof(float)));
+                c->tile_cap = need;
+            }
+            HIPCHK(c, hipStreamWaitEvent(c->tile_stream, c0->frame_ready, 0));
+            if (rows > 0) {
+                HIPCHK(c, hipMemsetAsync(c->tile_flags, 0, sizeof(uint32_t), c->tile_stream));
+                nwe_outputs o = {};
+                o.struct_bytes = sizeof(nwe_outputs);
+                float* t_rgb = c->tile_buf;
+                float* t_depth = t_rgb + (size_t)n_poses * px * 3;
+                float* t_acc = t_depth + (size_t)n_poses * px;
+                o.rgb = rgb_dev ? t_rgb : nullptr; o.depth = depth_dev ? t_depth : nullptr; o.acc = acc_dev ? t_acc : nullptr;
+                o.flags = c->tile_flags;
+                const int rc = nwe_render(c, c2w, n_poses, H, W, fx, fy, cx, cy, near, far, r0, r1, precision, &o, c->tile_stream);
+                if (rc) return rc;
+                // tile -> frame: pose p's rows [r0, r1) are contiguous in the row-major [n_poses, H, W, C] frame
+                for (int p = 0; p < n_poses; ++p) {
+                    const size_t dst_px = ((size_t)p * H + r0) * W, src_px = (size_t)p * px;
+                    if (rgb_dev)
+                        HIPCHK(c, hipMemcpyPeerAsync(rgb_dev + dst_px * 3, c0->device, t_rgb + src_px * 3, c->device, px * 3 * sizeof(float), c->tile_stream));
+                    if (depth_dev)
+                        HIPCHK(c, hipMemcpyPeerAsync(depth_dev + dst_px, c0->device, t_depth + src_px, c->device, px * sizeof(float), c->tile_stream));
+                    if (acc_dev)
+                        HIPCHK(c, hipMemcpyPeerAsync(acc_dev + dst_px, c0->device, t_acc + src_px, c->device, px * sizeof(float), c->tile_stream));
+                }
+                HIPCHK(c, hipMemcpyPeerAsync(c0->flag_parts + i, c0->device, c->tile_flags, c->device, sizeof(uint32_t), c->tile_stream));
+            }
+            HIPCHK(c, hipEventRecord(c->tile_done, c->tile_stream));
+            return NWE_OK;
+        };
+        rc_all = step();
+        if (rc_all != NWE_OK && c != c0) c0->err = "tile " + std::to_string(i) + ": " + c->err;
+        r0 = r1;
+    }
+    // the caller's stream continues when every tile has landed (also on the error path: nothing may still be writing)
+    (void)hipSetDevice(c0->device);
+    for (int i = 0; i < n_ctx; ++i)
+        if (ctxs[i]->tile_done) (void)hipStreamWaitEvent(stream0, ctxs[i]->tile_done, 0);
+    if (rc_all != NWE_OK) return rc_all;
+    if (flags_dev) {
+        hipLaunchKernelGGL(or_flags_kernel, dim3(1), dim3(1), 0, stream0, c0->flag_parts, n_ctx, flags_dev);
+        HIPCHK(c0, hipGetLastError());
+    }
+    return NWE_OK;
+}
+
 int nwe_create_rays(nwe_ctx* c, const float* c2w, int n_poses, int H, int W, float fx, float fy, float cx, float cy, float near,
                     float far, int row_begin, int row_end, float* rays_out_dev, void* stream) {
     if (!c || c->host_only) return fail(c, NWE_ERR_STATE, "needs a device context");
@@ -513,9 +624,11 @@ int64_t nwe_flops_per_eval(const nwe_ctx* c, int which) {
 float nwe_last_kernel_ms(nwe_ctx* c) {
     if (!c || c->host_only || c->last_slot < 0 || !c->slots[c->last_slot].used) return -1.f;
     const nwe_ctx::Slot& s = c->slots[c->last_slot];
-    if (hipEventSynchronize(s.ev1) != hipSuccess) return -1.f;
+    hipError_t e = hipSetDevice(c->device);
+    if (e == hipSuccess) e = hipEventSynchronize(s.ev1);
     float ms = -1.f;
-    if (hipEventElapsedTime(&ms, s.ev0, s.ev1) != hipSuccess) return -1.f;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, s.ev0, s.ev1);
+    if (e != hipSuccess) { c->err = std::string("nwe_last_kernel_ms: ") + hipGetErrorString(e); (void)hipGetLastError(); return -1.f; }
     return ms;
 }
 

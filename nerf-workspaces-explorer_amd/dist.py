@@ -45,8 +45,8 @@ def gather_tiles(tile: torch.Tensor, H: int, rank: int, world: int, dst: int = 0
     h_max = max(b - a for a, b in ranges)
     B, h, W, C = tile.shape
     assert h == ranges[rank][1] - ranges[rank][0], "tile height does not match this rank's row range"
-    if world == 1:
-        return tile
+    if world == 1 and not (dist.is_available() and dist.is_initialized()):
+        return tile            # no process group: plain single-process use.  With a group of one the collective below still runs.
     send = tile
     if h < h_max:
         send = torch.zeros((B, h_max, W, C), dtype=tile.dtype, device=tile.device)

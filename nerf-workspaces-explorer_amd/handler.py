@@ -16,6 +16,7 @@ Dropped side effects of the reference (none affects results): ``torch.cuda.empty
 from __future__ import annotations
 
 import math
+import os
 from typing import Dict, Mapping, Optional, Sequence, Tuple
 
 import numpy as np
@@ -25,7 +26,7 @@ from . import _lib
 from .camera_poses import get_camera_poses_from_list_of_coordinates
 from .config import Config, parse_product
 from .data_descriptors import COORD
-from .renderer import Renderer
+from .renderer import Renderer, TiledRenderer
 
 _FLAG_KEYS = {1 << 0: "rgb_fine", 1 << 1: "depth_fine", 1 << 2: "acc_fine", 1 << 3: "disp_fine", 1 << 4: "rgb_coarse",
               1 << 5: "depth_coarse", 1 << 6: "acc_coarse", 1 << 7: "disp_coarse", 1 << 8: "raw", 1 << 9: "z_std"}
@@ -47,10 +48,17 @@ def pinhole_intrinsics(H: int, W: int, hfov_deg: float = 90.0) -> Tuple[float, f
 
 class NeRFReplicaInferenceHandler:
 
-    def __init__(self, office_name: str, ckpt_path: str, device: int = 0, precision: str = "f16x3") -> None:
+    def __init__(self, office_name: str, ckpt_path: str, device: int = 0, precision: str = "f16x3",
+                 devices: Optional[Sequence[int]] = None) -> None:
+        """``devices`` (or the environment variable NWE_DEVICES, e.g. "0,1,2,3", for a caller that constructs the handler
+        with the reference's two arguments, application/workspace.py:28-29): render every frame as row tiles on these
+        devices from this one process (renderer.TiledRenderer); a device may be listed more than once."""
         self._office_name = office_name
         self._ckpt_path = ckpt_path
         self._device_index = device
+        if devices is None and os.environ.get("NWE_DEVICES"):
+            devices = [int(d) for d in os.environ["NWE_DEVICES"].split(",") if d.strip() != ""]
+        self._devices = list(devices) if devices else None
         if precision not in _lib.PRECISIONS:
             raise ValueError(f"precision must be one of {sorted(_lib.PRECISIONS)}")
         self._precision = precision
@@ -101,7 +109,7 @@ class NeRFReplicaInferenceHandler:
             except FileNotFoundError as exc:
                 raise RuntimeError(f"Checkpoint path: {self._ckpt_path} for model cannot be found!") from exc
         if self._renderer is None:
-            self._renderer = Renderer(self._device_index)
+            self._renderer = TiledRenderer(self._devices) if self._devices else Renderer(self._device_index)
         if getattr(self, "_fold", True) is False:
             self._renderer.debug_set_fold(False)
         coarse, fine = state_dicts

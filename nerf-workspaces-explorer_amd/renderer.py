@@ -293,3 +293,69 @@ class Renderer:
         rep = (C.c_int32 * 8)()
         rc = self._lib.nwe_selftest(self._ctx, rep)
         return rc, list(rep)
+
+
+class TiledRenderer:
+    """Several HIP contexts in ONE process - one per device, or several on one device - that render one frame together:
+    context i renders the row tile ``dist.shard_rows(H, n)[i]`` of every pose on its own stream and the tiles are copied
+    into full frames on the first device (``nwe_render_tiled``: hipMemcpyPeerAsync over xGMI).  This is the multi-GPU path
+    of the reference's synchronous GUI call (application/app.py:336 -> workspace.py:66 -> render_coordinates), which cannot
+    be a torchrun rank; one process per GPU with an RCCL gather is ``nwe_amd.dist``.
+
+    ``devices`` lists the device of every tile, e.g. ``[0, 1, 2, 3]`` or, for tests on a one-GPU box, ``[0, 0, 0]``.
+    The first renderer doubles as the single-context surface (``render_rays``, ``to8b``, ``create_rays`` ...)."""
+
+    def __init__(self, devices: Sequence[int]):
+        if not devices:
+            raise ValueError("TiledRenderer needs at least one device")
+        self.parts = [Renderer(int(d)) for d in devices]
+        self.devices = [int(d) for d in devices]
+        self._lib = self.parts[0]._lib
+        self._ctxs = (C.c_void_p * len(self.parts))(*[p._ctx for p in self.parts])
+
+    def __getattr__(self, name):            # everything else: the first context (same device as the assembled frames)
+        return getattr(self.parts[0], name)
+
+    def close(self) -> None:
+        for p in self.parts:
+            p.close()
+
+    def set_network(self, which: int, state_dict: Mapping[str, object]):
+        return [p.set_network(which, state_dict) for p in self.parts][0]
+
+    def set_sampling(self, n_samples: int, n_importance: int) -> None:
+        for p in self.parts:
+            p.set_sampling(n_samples, n_importance)
+
+    def set_white_background(self, on: bool) -> None:
+        for p in self.parts:
+            p.set_white_background(on)
+
+    def debug_set_fold(self, on: bool) -> None:
+        for p in self.parts:
+            p.debug_set_fold(on)
+
+    def render(self, c2w, H: int, W: int, *, fx: float, fy: float, cx: float, cy: float, near: float, far: float,
+               rows: Optional[Tuple[int, int]] = None, precision: str = "f16x3",
+               outputs: Sequence[str] = ("rgb", "depth", "acc")) -> Dict[str, torch.Tensor]:
+        """Whole frames [B*H*W, ...] on the first device.  A caller that asks for a row range, or for outputs other than
+        rgb / depth / acc, gets the single-context path (those are test and diagnostic surfaces)."""
+        if rows is not None or not set(outputs) <= {"rgb", "depth", "acc"}:
+            return self.parts[0].render(c2w, H, W, fx=fx, fy=fy, cx=cx, cy=cy, near=near, far=far, rows=rows, precision=precision,
+                                        outputs=outputs)
+        poses = np.ascontiguousarray(np.asarray(c2w, dtype=np.float32).reshape(-1, 4, 4))
+        first = self.parts[0]
+        n = poses.shape[0] * H * W
+        with torch.cuda.device(first.device):
+            res = {k: torch.empty((n, 3) if k == "rgb" else (n,), dtype=torch.float32, device=first.device) for k in outputs}
+            res["flags"] = torch.zeros(1, dtype=torch.int32, device=first.device)
+            ptr = lambda k: res[k].data_ptr() if k in res else None
+            stream = torch.cuda.current_stream(first.device).cuda_stream
+            rc = self._lib.nwe_render_tiled(self._ctxs, len(self.parts), poses.ctypes.data, poses.shape[0], H, W, fx, fy, cx, cy, near,
+                                            far, _lib.PRECISIONS[precision], ptr("rgb"), ptr("depth"), ptr("acc"), ptr("flags"), stream)
+        first._check(rc, "nwe_render_tiled")
+        return res
+
+    def tile_kernel_ms(self):
+        """Kernel time of every tile of the last frame (HIP events on the tiles' own streams)."""
+        return [p.last_kernel_ms() for p in self.parts]

@@ -10,7 +10,7 @@ coordinates, un-rotates by the plan/scene angle, and looks around with the GUI's
 from __future__ import annotations
 
 import os
-from typing import Dict, NamedTuple, Optional, Tuple
+from typing import Dict, NamedTuple, Optional, Sequence, Tuple
 
 import numpy as np
 
@@ -49,15 +49,17 @@ def click_to_coordinates(office: str, rel_x: float, rel_y: float, hor_angle: flo
 
 
 class Workspace:
-    def __init__(self, name: str, model_path: Optional[str] = None, device: int = 0, precision: str = "f16x3") -> None:
+    def __init__(self, name: str, model_path: Optional[str] = None, device: int = 0, precision: str = "f16x3",
+                 devices: Optional[Sequence[int]] = None) -> None:
         if name not in OFFICES:
             raise KeyError(f"unknown workspace {name!r}; known: {sorted(OFFICES)}")
         self._name = name
         self._office_name = name.replace(" ", "_").lower()
         # same default location as the reference: nerf/final_models/<office>/model.ckpt under the project root
         self._model_path = model_path or os.path.normpath(os.path.join(os.getcwd(), "nerf", "final_models", self._office_name, "model.ckpt"))
+        # devices (or NWE_DEVICES): render_image() renders row tiles on several GPUs from this one (GUI) process
         self._nerf_inference = NeRFReplicaInferenceHandler(office_name=self._office_name, ckpt_path=self._model_path, device=device,
-                                                           precision=precision)
+                                                           precision=precision, devices=devices)
 
     def __repr__(self) -> str:
         return self._name

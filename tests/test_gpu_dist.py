@@ -3,6 +3,7 @@ import os
 import subprocess
 import sys
 
+import numpy as np
 import pytest
 
 
@@ -19,3 +20,38 @@ def test_row_tiles_across_processes_equal_the_single_process_frame(world):
     print(p.stdout[-2000:], p.stderr[-2000:])
     assert p.returncode == 0
     assert p.stdout.count("equal to the single-process frame: True") == 3
+
+
+@pytest.mark.gpu
+def test_gather_tiles_device_branch_under_rccl():
+    """dist.gather_tiles keeps the slabs on the device under the nccl (= RCCL) backend; every other test drives it with gloo
+    and host tensors.  RCCL does not take two ranks on one device, so on the one-GPU box the branch is driven by a process
+    group of ONE rank: same code (padding to the largest tile, dist.gather of device tensors, reassembly), no peer."""
+    import socket
+    import torch
+    import torch.distributed as dist
+    from nwe_amd.dist import TileShardedRenderer, gather_tiles
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        assert dist.get_backend() == "nccl"
+        tile = torch.arange(2 * 5 * 7 * 5, dtype=torch.float32, device="cuda").reshape(2, 5, 7, 5)
+        full = gather_tiles(tile, 5, 0, 1)
+        assert full.is_cuda and torch.equal(full, tile)
+        # and through the renderer wrapper with the real kernel
+        import nwe_amd
+        h = nwe_amd.NeRFReplicaInferenceHandler("office_tokyo", "synthetic")
+        h.set_sampling(16, 8)
+        h.initialize_models(state_dicts=(nwe_amd.synthetic.thin_fog(nwe_amd.synthetic.make_state_dict(1000, 4, 128)),
+                                         nwe_amd.synthetic.make_state_dict(1001, 4, 128)))
+        tsr = TileShardedRenderer(lambda poses, hh, ww, rows: h.render_batch(poses, hh, ww, rows=rows), 0, 1)
+        pose = np.eye(4, dtype=np.float32)[None]
+        got = tsr.render_frames(pose, 12, 16)
+        want = h.render_batch(pose, 12, 16)
+        assert got["rgb"].is_cuda and torch.equal(got["rgb"], want["rgb"]) and torch.equal(got["depth"], want["depth"])
+    finally:
+        dist.destroy_process_group()

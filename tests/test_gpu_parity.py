@@ -817,3 +817,126 @@ def test_importance_sampling_on_the_reference_edge_vectors(r_c3, golden_dir, pre
         assert (out["z_fine"].cpu() - want).abs().max().item() <= 1e-6
     finally:
         r_c3.debug_set_decomposition(-1)
+
+
+@pytest.mark.gpu
+def test_c4_full_size_row_tiles_equal_the_frame(r_c3):
+    """BASELINE config 4 at its stated size on ONE GPU: the 800x800 frame rendered as the 8 row tiles of
+    dist.shard_rows(800, 8) - exactly what the 8 ranks render - equals the whole frame bit for bit; each tile's kernel time
+    is the per-rank latency of config 4 (80 000 rays = 2.4 rounds of 128-ray workgroups; the launcher's plan for it)."""
+    from nwe_amd.dist import shard_rows
+    fx, fy, cx, cy = O.intrinsics(800, 800)
+    pose = O.camera_pose((0.0, -0.5, -0.77, 0.0, -90.0, 0.0), (0, 0, 0, -30.0, 0.0, 0.0))[0].numpy()
+    kw = dict(fx=fx, fy=fy, cx=cx, cy=cy, near=0.1, far=10.0, outputs=("rgb", "depth", "acc"))
+    whole = r_c3.render(pose, 800, 800, **kw)
+    t_whole = r_c3.last_kernel_ms()
+    tiles, ms = [], []
+    for rr in shard_rows(800, 8):
+        tiles.append(r_c3.render(pose, 800, 800, rows=rr, **kw))
+        ms.append(r_c3.last_kernel_ms())
+    for k in ("rgb", "depth", "acc"):
+        assert torch.equal(torch.cat([t[k] for t in tiles]), whole[k]), k
+    print(f"C4 on one GPU: whole frame {t_whole:.1f} ms; the 8 row tiles {', '.join(f'{m:.1f}' for m in ms)} ms "
+          f"(sum {sum(ms):.1f}, slowest {max(ms):.1f} = the frame latency on 8 GPUs before the gather)")
+    assert int(whole["flags"].item()) & 0x7 == 0          # rgb, depth, acc finite (disp = 1/(depth/acc) may be NaN where acc = 0, like the reference)
+    assert max(ms) < 0.2 * t_whole          # a tile is 1/8 of the rays: not more than 1.6 eighths of the frame's time
+
+
+@pytest.mark.gpu
+def test_c5_full_size_pose_sweep_in_one_launch(r_c3):
+    """BASELINE config 5 at its stated size on ONE GPU: 32 poses of the GUI turn-left sweep (11.25 degree steps)
+    x 800x800 x (64+128), 8x256, rendered by ONE launch (20.5 M rays, 160 000 workgroups), against per-pose renders."""
+    fx, fy, cx, cy = O.intrinsics(800, 800)
+    init = nwe_amd.COORD(x=0.0, y=-0.5, z=-0.75 / np.cos(-10.0 / 180.0 * np.pi), pitch=-90.0)
+    poses = nwe_amd.get_camera_poses_from_list_of_coordinates(init, [nwe_amd.COORD(yaw=-11.25 * k) for k in range(32)]).numpy()
+    kw = dict(fx=fx, fy=fy, cx=cx, cy=cy, near=0.1, far=10.0, outputs=("rgb", "depth"))
+    batch = r_c3.render(poses, 800, 800, **kw)
+    ms = r_c3.last_kernel_ms()
+    rgb = batch["rgb"].reshape(32, 800 * 800, 3)
+    depth = batch["depth"].reshape(32, 800 * 800)
+    print(f"C5 on one GPU: 32 frames in one launch {ms:.0f} ms = {32e3 / ms:.2f} frames/s, {32 * 640000 * 192 / (ms * 1e-3):.3e} ray-samples/s")
+    for k in (0, 13, 31):
+        one = r_c3.render(poses[k], 800, 800, **kw)
+        assert torch.equal(one["rgb"], rgb[k]) and torch.equal(one["depth"], depth[k]), k
+    assert int(batch["flags"].item()) & 0x7 == 0
+    assert (rgb[0] - rgb[16]).abs().max() > 1e-3          # opposite views differ
+
+
+@pytest.mark.gpu
+def test_reference_format_checkpoint_through_the_handler(tmp_path):
+    """SURVEY 8(f2) on the device: a checkpoint written the way the reference's training handler writes it
+    (nerf_replica_training_handler.py:404-407, keys WITHOUT the leading underscore, handler.py:150-164) is found at
+    ckpt_path, loaded by initialize_models() (weights_only=True), and renders the same frame as the same weights passed
+    as state dicts."""
+    sd_c, sd_f = nwe_amd.synthetic.thin_fog(_sd(21, 8, 256)), _sd(22, 8, 256)
+    strip = lambda sd: {k[1:]: torch.from_numpy(v) for k, v in sd.items()}
+    path = os.path.join(tmp_path, "model.ckpt")
+    torch.save({"global_step": 200000, "network_coarse_state_dict": strip(sd_c), "network_fine_state_dict": strip(sd_f),
+                "optimizer_state_dict": {"state": {}, "param_groups": []}}, path)
+    h = nwe_amd.NeRFReplicaInferenceHandler("office_tokyo", path)
+    h.initialize_models()                                                    # no state_dicts=: reads the file
+    init = nwe_amd.COORD(x=0.0, y=-0.5, z=-0.76, yaw=0.0, pitch=-90.0, roll=0.0)
+    img = h.render_coordinates(init, nwe_amd.COORD(yaw=-30.0))
+    h2 = nwe_amd.NeRFReplicaInferenceHandler("office_tokyo", "unused")
+    h2.initialize_models(state_dicts=(sd_c, sd_f))
+    assert np.array_equal(img, h2.render_coordinates(init, nwe_amd.COORD(yaw=-30.0)))
+    pose = nwe_amd.get_camera_poses_from_list_of_coordinates(init, [nwe_amd.COORD(yaw=-30.0)])[0].numpy()
+    assert torch.equal(h.render(pose)["rgb"], h2.render(pose)["rgb"])
+    h.initialize_models()                                                    # the GUI calls it on every window open (app.py:116)
+    assert np.array_equal(img, h.render_coordinates(init, nwe_amd.COORD(yaw=-30.0)))
+
+
+@pytest.mark.gpu
+def test_one_context_two_streams_back_to_back(r_c3):
+    """Launches of ONE context queued on different streams do not share a pose table: two renders with different poses
+    issued back to back on two streams give what the same renders give one after the other."""
+    fx, fy, cx, cy = O.intrinsics(96, 128)
+    p = [O.camera_pose((0.0, -0.5, -0.77, 0.0, -90.0, 0.0), (0, 0, 0, a, 0.0, 0.0))[0].numpy() for a in (0.0, -60.0, -120.0)]
+    kw = dict(fx=fx, fy=fy, cx=cx, cy=cy, near=0.1, far=10.0, outputs=("rgb",))
+    want = [r_c3.render(q, 96, 128, **kw)["rgb"].clone() for q in p]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream() for _ in p]
+    got = []
+    for _ in range(2):                                   # twice: the second round reuses the slots of the first
+        got.clear()
+        for q, st in zip(p, streams):
+            with torch.cuda.stream(st):
+                got.append(r_c3.render(q, 96, 128, **kw)["rgb"])
+        torch.cuda.synchronize()
+        for a, b in zip(got, want):
+            assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
+def test_in_process_tiles_through_the_workspace_call():
+    """The in-process multi-device path (nwe_render_tiled) behind the reference's synchronous GUI call
+    (application/app.py:336 -> Workspace.render_image -> render_coordinates): N contexts in one process, each rendering its
+    row tile on its own stream, tiles copied into the frame with hipMemcpyPeerAsync.  On the one-GPU test box the N
+    "devices" are the same card ([0, 0, 0] - the same code path as [0, 1, 2]); frames equal the single-context frames bit
+    for bit, for ragged tile heights (240 rows over 7 tiles), batches of poses, and through NWE_DEVICES."""
+    sds = (nwe_amd.synthetic.thin_fog(_sd(1000, 8, 256)), _sd(1001, 8, 256))
+    one = nwe_amd.Workspace("Office Tokyo")
+    one.initialize_models(state_dicts=sds)
+    want = one.render_image(0.4, 0.6, 30, 0)
+    for devices in ([0], [0, 0, 0], [0] * 7):
+        ws = nwe_amd.Workspace("Office Tokyo", devices=devices)
+        ws.initialize_models(state_dicts=sds)
+        got = ws.render_image(0.4, 0.6, 30, 0)
+        assert np.array_equal(got, want), devices
+        print("tiles", len(devices), "kernel ms per tile", [round(m, 2) for m in ws.handler.renderer.tile_kernel_ms()])
+    # float frames, several poses, depth and acc, non-default size
+    init, loc = one.transform_relative_coordinates(0.4, 0.6, 30, 0)
+    poses = nwe_amd.get_camera_poses_from_list_of_coordinates(init, [nwe_amd.COORD(yaw=-30.0 * k) for k in range(3)]).numpy()
+    a = one.handler.render_batch(poses, 50, 64)
+    b = ws.handler.render_batch(poses, 50, 64)
+    for k in ("rgb", "depth", "acc"):
+        assert torch.equal(a[k], b[k]), k
+    assert int(b["flags"].item()) == int(a["flags"].item())
+    os.environ["NWE_DEVICES"] = "0,0"
+    try:
+        env = nwe_amd.NeRFReplicaInferenceHandler("office_tokyo", "unused")          # the reference's two-argument construction
+        env.initialize_models(state_dicts=sds)
+        assert isinstance(env.renderer, nwe_amd.TiledRenderer) and len(env.renderer.parts) == 2
+        assert np.array_equal(env.render_coordinates(init, loc), want)
+    finally:
+        del os.environ["NWE_DEVICES"]
