@@ -229,8 +229,9 @@ struct FineSampler {
         }
         return acc;
     }
-    __device__ __forceinline__ void prepare(const Ray& r) {
-        // weights[..., 1:-1] + 1e-5, normalised, cumulative (double accumulator, float per element)
+    __device__ __forceinline__ void prepare(const Ray& r) { build_cdf(); start(r); }
+    // weights[..., 1:-1] + 1e-5, normalised, cumulative (double accumulator, float per element), in place
+    __device__ __forceinline__ void build_cdf() {
         const float sum = torch_sum_order(ns - 2);
         double run = 0.0;
         wc[0] = 0.f;                                                         // rays.py:90 leading zero
@@ -238,6 +239,8 @@ struct FineSampler {
             run += (double)__fdiv_rn(__fadd_rn(wc[i * stride], 1e-5f), sum);
             wc[i * stride] = (float)run;
         }
+    }
+    __device__ __forceinline__ void start(const Ray& r) {
         ci = 0; fj = 0; ptr = 0;
         cur_f = sample(r, 0, ptr, nullptr);
     }

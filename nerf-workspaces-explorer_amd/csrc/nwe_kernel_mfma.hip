@@ -733,17 +733,22 @@ __device__ __forceinline__ void mlp_eval(WalkerT& wk, Frags& F, int lane, float 
     o_b = pend_value(P1, 2, inv_scale);
 }
 
-constexpr int kMfmaMaxSamples = 64;   // coarse samples the per-wave LDS weight buffer is sized for
+// Coarse samples the LDS weight / cdf buffer holds: four packets per workgroup keep one buffer per wave (64 samples); the
+// sample-split decomposition has ONE packet per workgroup and one shared buffer, which holds the ABI's full 128 samples
+// in half the space - so more than 64 coarse samples always take that decomposition (launch_t).
+constexpr int kPacketMaxSamples = 64;
+constexpr int kSplitMaxSamples = kMaxSamples;
 
-template <int W, int D>
+template <int W, int D, bool SPLIT>
 struct Smem {
     using S = Shape<W, D>;
+    static constexpr int WBYTES = (SPLIT ? kSplitMaxSamples : kWaves * kPacketMaxSamples) * kRaysPerWave * 4;
     static constexpr int CHUNKS = 2 * S::CHUNK_BYTES;
     static constexpr int BOFF = CHUNKS;                                              // bias tables, coarse then fine
     static constexpr int BIAS_BYTES = ((S::N_CHUNKS * 32 * 4 + 255) / 256) * 256;
     static constexpr int WOFF = BOFF + 2 * BIAS_BYTES;                               // per-wave coarse weights / cdf
-    static constexpr int TOFF = WOFF + kWaves * kMfmaMaxSamples * kRaysPerWave * 4;  // t, 1-t, u tables
-    static constexpr int XOFF = TOFF + (2 * kMfmaMaxSamples + kMaxImportance) * 4;     // sample-split mode: shaded samples, 2 buffers
+    static constexpr int TOFF = WOFF + WBYTES;                                       // t, 1-t, u tables
+    static constexpr int XOFF = TOFF + (2 * kMaxSamples + kMaxImportance) * 4;         // sample-split mode: shaded samples, 2 buffers
     static constexpr int LOFF = XOFF + 2 * kWaves * kRaysPerWave * 16;               // three tail slots of two tiles (Walker)
     static constexpr int TOTAL = LOFF + 3 * 2 * kTileBytes;
     static_assert(XOFF % 16 == 0 && LOFF % 16 == 0 && TOTAL <= 160 * 1024, "LDS budget");
@@ -759,7 +764,7 @@ struct Smem {
 template <int W, int D, int SKIP, bool X3, bool SPLIT, bool FOLD>
 __global__ void __launch_bounds__(256) render_mfma_kernel(RenderArgs a, NetMfma nc, NetMfma nf) {
     using S = Shape<W, D>;
-    using SM = Smem<W, D>;
+    using SM = Smem<W, D, SPLIT>;
     __shared__ __attribute__((aligned(16))) char smem[SM::TOTAL];
 
     const int lane = threadIdx.x & 63;
@@ -768,8 +773,8 @@ __global__ void __launch_bounds__(256) render_mfma_kernel(RenderArgs a, NetMfma 
     const int ns = a.n_samples, ni = a.n_importance;
 
     float* s_t = reinterpret_cast<float*>(smem + SM::TOFF);
-    float* s_omt = s_t + kMfmaMaxSamples;
-    float* s_u = s_omt + kMfmaMaxSamples;
+    float* s_omt = s_t + kMaxSamples;
+    float* s_u = s_omt + kMaxSamples;
     for (int i = threadIdx.x; i < ns; i += 256) { s_t[i] = a.t_vals[i]; s_omt[i] = a.omt_vals[i]; }
     for (int i = threadIdx.x; i < ni; i += 256) s_u[i] = a.u_vals[i];
     float* s_bias = reinterpret_cast<float*>(smem + SM::BOFF);
@@ -799,7 +804,10 @@ __global__ void __launch_bounds__(256) render_mfma_kernel(RenderArgs a, NetMfma 
     encode<2, S::KD, X3>(ray.vx, ray.vy, ray.vz, half, GDhi, GDlo);
 
     FineSampler fs;
-    fs.wc = reinterpret_cast<float*>(smem + SM::WOFF) + wave * (kMfmaMaxSamples * kRaysPerWave) + (lane & 31);
+    // coarse weights, then the cdf: one buffer per wave (= per packet), or ONE for the workgroup's single packet (SPLIT), which
+    // wave 0 alone writes - all four waves compute the same values - and everyone reads behind a workgroup barrier
+    fs.wc = reinterpret_cast<float*>(smem + SM::WOFF) + (SPLIT ? 0 : wave * (kPacketMaxSamples * kRaysPerWave)) + (lane & 31);
+    const bool wc_writer = !SPLIT || wave == 0;
     fs.stride = kRaysPerWave; fs.u_tab = s_u; fs.ns = ns; fs.ni = ni;
     fs.cd.t_tab = s_t; fs.cd.omt_tab = s_omt; fs.cd.ns = ns;
     fs.cd.jitter = a.t_rand; fs.cd.row = row;                         // training-mode forward: host-drawn random rows
@@ -819,7 +827,7 @@ __global__ void __launch_bounds__(256) render_mfma_kernel(RenderArgs a, NetMfma 
         const float* noise = pass == 0 ? a.noise_c : a.noise_f;
         const float* raw_in = pass == 0 ? a.raw_in_c : a.raw_in_f;   // test hook: network outputs from the caller (uniform)
         if (pass == 0 && a.w_in) {                                   // test hook: coarse weights from the caller, no coarse pass
-            for (int s = 0; s < ns; ++s) fs.wc[s * kRaysPerWave] = a.w_in[rclamp * ns + s];
+            if (wc_writer) for (int s = 0; s < ns; ++s) fs.wc[s * kRaysPerWave] = a.w_in[rclamp * ns + s];
             continue;
         }
         comp.reset();
@@ -833,7 +841,9 @@ __global__ void __launch_bounds__(256) render_mfma_kernel(RenderArgs a, NetMfma 
                 return a.z_fine_in ? a.z_fine_in[rclamp * Stot + i] : fs.next(ray);
             };
             if (pass == 1) {
-                fs.prepare(ray);
+                if (wc_writer) fs.build_cdf();     // in place: one wave, then everyone reads
+                __syncthreads();
+                fs.start(ray);
                 if (wants_survey(a.out)) {
                     const SampleSurvey sv = fs.survey(ray);
                     if (live) flags |= store_survey(a.out, ridx, sv);
@@ -853,7 +863,7 @@ __global__ void __launch_bounds__(256) render_mfma_kernel(RenderArgs a, NetMfma 
                     if (si < Stot) {
                         const float w = comp.accumulate(x[k * kRaysPerWave], zp[k]);
                         if (pass == 0) {
-                            fs.wc[si * kRaysPerWave] = w;
+                            if (wc_writer) fs.wc[si * kRaysPerWave] = w;
                             if (live && a.out.weights_coarse) a.out.weights_coarse[ridx * ns + si] = w;
                         }
                     }
@@ -1048,7 +1058,7 @@ bool mfma_supported(int D, int W, int in_xyz, int in_dir, int skip, bool folded)
     return folded || (D == 8 && W == 256) || (D == 4 && W == 128);
 }
 
-int mfma_max_samples() { return kMfmaMaxSamples; }
+int mfma_max_samples() { return kSplitMaxSamples; }
 
 template <int W, int D, int SKIP, bool FOLD>
 static void launch_one(RenderArgs a, const NetMfma& nc, const NetMfma& nf, bool three_pass, bool split, int64_t ray_first, int64_t rays,
@@ -1089,6 +1099,7 @@ static bool launch_t(const RenderArgs& a, const NetMfma& nc, const NetMfma& nf, 
     const double t_single = t_packet <= t_split ? t_packet : t_split;
     int plan = t_hybrid < 0.97 * t_single ? 2 : (t_packet <= t_split ? 0 : 1);
     if (decomposition >= 0) plan = decomposition;   // nwe_debug_set_decomposition: tests force one
+    if (a.n_samples > kPacketMaxSamples) plan = 1;  // only the single-packet workgroup has LDS for that many coarse weights
     if (plan == 2) {
         launch_one<W, D, SKIP, FOLD>(a, nc, nf, three_pass, false, 0, full, stream);
         launch_one<W, D, SKIP, FOLD>(a, nc, nf, three_pass, true, full, a.n_rays - full, stream);
@@ -1100,7 +1111,7 @@ static bool launch_t(const RenderArgs& a, const NetMfma& nc, const NetMfma& nf, 
 
 bool launch_render_mfma(const RenderArgs& a, const NetMfma& nc, const NetMfma& nf, bool three_pass, int decomposition, hipStream_t stream) {
     if (a.n_importance > 0 && (nf.D != nc.D || nf.W != nc.W || nf.skip != nc.skip || nf.folded != nc.folded)) return false;
-    if (a.n_samples > kMfmaMaxSamples) return false;
+    if (a.n_samples > kSplitMaxSamples) return false;
     const int D = nc.D, W = nc.W, skip = nc.skip;
     if (nc.folded) {
         if (D == 8 && W == 256 && skip == 4) return launch_t<256, 8, 4, true>(a, nc, nf, three_pass, decomposition, stream);

@@ -608,7 +608,7 @@ def test_repeated_renders_are_bit_identical(r_c3):
 @pytest.mark.gpu
 def test_randomised_sampling_configurations_against_live_oracle():
     """Edge geometry the fixed goldens do not reach: odd and tiny sample counts (Ns=3 is the smallest sample_pdf accepts,
-    rays.py:87), Ni > Ns, Ni = 1, non-unit ray directions, near/far other than the YAML's, a ragged ray count; MFMA path
+    rays.py:87), the ABI's largest (Ns=128), Ni > Ns, Ni = 1, non-unit ray directions, near/far other than the YAML's, a ragged ray count; MFMA path
     against the oracle run live on the same rays (thin-fog coarse net: well-conditioned sampling, every ray compared)."""
     rng = np.random.default_rng(20240)
     sd_c = nwe_amd.synthetic.thin_fog(_sd(1000, 8, 256))
@@ -617,7 +617,9 @@ def test_randomised_sampling_configurations_against_live_oracle():
     r.set_network(0, sd_c)
     r.set_network(1, sd_f)
     for ns, ni, near, far, n_rays in [(3, 5, 0.1, 10.0, 70), (5, 1, 0.5, 4.0, 33), (64, 256, 0.1, 10.0, 45), (17, 40, 0.05, 6.0, 129),
-                                      (33, 2, 1.0, 2.0, 64), (64, 0, 0.1, 10.0, 50), (4, 0, 0.1, 10.0, 31)]:
+                                      (33, 2, 1.0, 2.0, 64), (64, 0, 0.1, 10.0, 50), (4, 0, 0.1, 10.0, 31),
+                                      # more than 64 coarse samples: the MFMA kernel's single-packet workgroup (shared cdf buffer)
+                                      (128, 128, 0.1, 10.0, 61), (65, 7, 0.2, 5.0, 40), (100, 0, 0.1, 10.0, 33)]:
         r.set_sampling(ns, ni)
         o = rng.uniform(-1.0, 1.0, (n_rays, 3)).astype(np.float32)
         d = (rng.normal(size=(n_rays, 3)) * rng.uniform(0.2, 3.0, (n_rays, 1))).astype(np.float32)   # |d| from 0.2 to ~5
@@ -717,9 +719,9 @@ def test_integration_md_ctypes_stub_runs(r_c3):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("D,Wn", [(8, 128), (4, 256)])
+@pytest.mark.parametrize("D,Wn", [(8, 128), (4, 256), (6, 256), (6, 128)])
 def test_further_mfma_shapes(D, Wn):
-    """8x128 (skip after layer 4) and 4x256 (no skip layer, as NeRFModel builds it for D <= 5): MFMA instantiations against
+    """8x128 and 6-deep trunks (skip after layer 4) and 4x256 (no skip layer, as NeRFModel builds it for D <= 5): MFMA instantiations against
     the fp32 kernel and the live oracle on the same rays, both decompositions."""
     sd_c = nwe_amd.synthetic.thin_fog(_sd(1000, D, Wn))
     sd_f = _sd(1001, D, Wn)
@@ -940,3 +942,33 @@ def test_in_process_tiles_through_the_workspace_call():
         assert np.array_equal(env.render_coordinates(init, loc), want)
     finally:
         del os.environ["NWE_DEVICES"]
+
+
+@pytest.mark.gpu
+def test_folded_feature_layer_against_the_unfolded_formulation():
+    """The product path multiplies _feature_linear into the view layer at pack time (nerf_model.py:64-70: no activation in
+    between; fp64 product on the host).  Against the kernel that evaluates the feature layer as the reference formulates
+    it, on the FULL C3 frame (640 000 rays, thin-fog coarse network so that every ray is comparable): raw network outputs
+    <= 2e-6, rgb <= 1e-5 on every ray."""
+    sd_c, sd_f = nwe_amd.synthetic.thin_fog(_sd(1000, 8, 256)), _sd(1001, 8, 256)
+    fx, fy, cx, cy = O.intrinsics(800, 800)
+    pose = O.camera_pose((0.0, -0.5, -0.77, 0.0, -90.0, 0.0), (0, 0, 0, -30.0, 0.0, 0.0))[0].numpy()
+    res = {}
+    for fold in (True, False):
+        r = nwe_amd.Renderer(0)
+        r.debug_set_fold(fold)
+        r.set_network(0, sd_c)
+        r.set_network(1, sd_f)
+        r.set_sampling(64, 128)
+        assert r.packed_stream(0).size == (2112 if fold else 2368) * 1024
+        res[fold] = r.render(pose, 800, 800, fx=fx, fy=fy, cx=cx, cy=cy, near=0.1, far=10.0, outputs=("rgb", "depth", "acc"))
+        ms = r.last_kernel_ms()
+        small = r.render(pose, 800, 800, fx=fx, fy=fy, cx=cx, cy=cy, near=0.1, far=10.0, rows=(400, 402), outputs=("raw_coarse", "raw_fine"))
+        res[fold].update(small)
+        print("folded" if fold else "unfolded", f"{ms:.1f} ms")
+        r.close()
+    d_rgb = (res[True]["rgb"] - res[False]["rgb"]).abs().max().item()
+    d_raw = max((res[True][k] - res[False][k]).abs().max().item() for k in ("raw_coarse", "raw_fine"))
+    d_depth = (res[True]["depth"] - res[False]["depth"]).abs().max().item()
+    print(f"folded vs unfolded, 640 000 rays: rgb {d_rgb:.2e}, depth {d_depth:.2e}, raw (1600 rays) {d_raw:.2e}")
+    assert d_raw <= 2e-6 and d_rgb <= 1e-5 and d_depth / FAR <= 1e-5
