@@ -57,36 +57,56 @@ __device__ __forceinline__ float norm3(float x, float y, float z) {
     return __builtin_sqrtf(__fmaf_rn(z, z, __fmaf_rn(y, y, __fmul_rn(x, x))));   // __fsqrt_rn is the NATIVE (1-ulp) sqrt in HIP
 }
 
-// nerf/rays/rays.py:6-71.  idx is the ray index inside the call.
-__device__ __forceinline__ Ray load_ray(const RenderArgs& a, int64_t idx) {
+// A ray is kept between uses as its SEED - three registers - and expanded where it is needed (make_ray): the render
+// kernels' per-ray state must not stay in registers across an MLP evaluation, which needs all of them.
+struct RaySeed {
+    int pose;     // pose index (pinhole mode) / row of the ray table (precomputed rays)
+    float x, y;   // camera-space direction ((w-cx)/fx, (h-cy)/fy, 1), pinhole mode only
+};
+
+// nerf/rays/rays.py:35-58.  idx is the ray index inside the call.
+__device__ __forceinline__ RaySeed seed_ray(const RenderArgs& a, int64_t idx) {
+    RaySeed s;
+    if (a.rays) { s.pose = (int)idx; s.x = s.y = 0.f; return s; }
+    const int per_pose = a.rows * a.W;
+    s.pose = (int)(idx / per_pose);
+    const int rem = (int)(idx - (int64_t)s.pose * per_pose);
+    const int h = a.row_begin + rem / a.W, w = rem % a.W;
+    // rays.py:52-56: ((w-cx)/fx, (h-cy)/fy, 1), true divisions
+    s.x = __fdiv_rn(__fsub_rn((float)w, a.cx), a.fx);
+    s.y = __fdiv_rn(__fsub_rn((float)h, a.cy), a.fy);
+    return s;
+}
+
+// nerf/rays/rays.py:6-32, :61-71.  VIEW: also the normalised view direction (rays.py:24), needed once per ray for gamma(d).
+template <bool VIEW>
+__device__ __forceinline__ Ray make_ray(const RenderArgs& a, const RaySeed& s) {
     Ray r;
+    r.vx = r.vy = r.vz = 0.f;
     if (a.rays) {  // handler.py:210-214: columns [o d near far viewdir]
-        const float* p = a.rays + idx * 11;
+        const float* p = a.rays + (int64_t)s.pose * 11;
         r.ox = p[0]; r.oy = p[1]; r.oz = p[2];
         r.dx = p[3]; r.dy = p[4]; r.dz = p[5];
         r.near = p[6]; r.far = p[7];
-        r.vx = p[8]; r.vy = p[9]; r.vz = p[10];
+        if (VIEW) { r.vx = p[8]; r.vy = p[9]; r.vz = p[10]; }
     } else {
-        const int per_pose = a.rows * a.W;
-        const int pose = (int)(idx / per_pose);
-        const int rem = (int)(idx - (int64_t)pose * per_pose);
-        const int h = a.row_begin + rem / a.W, w = rem % a.W;
-        const float* m = a.poses + pose * 16;
-        // rays.py:52-56: ((w-cx)/fx, (h-cy)/fy, 1), true divisions
-        const float x = __fdiv_rn(__fsub_rn((float)w, a.cx), a.fx);
-        const float y = __fdiv_rn(__fsub_rn((float)h, a.cy), a.fy);
+        const float* m = a.poses + s.pose * 16;
         // rays.py:67: 3x3 @ 3x1 as torch's CPU bmm does it: products summed left to right, no FMA
-        r.dx = __fadd_rn(__fadd_rn(__fmul_rn(m[0], x), __fmul_rn(m[1], y)), m[2]);
-        r.dy = __fadd_rn(__fadd_rn(__fmul_rn(m[4], x), __fmul_rn(m[5], y)), m[6]);
-        r.dz = __fadd_rn(__fadd_rn(__fmul_rn(m[8], x), __fmul_rn(m[9], y)), m[10]);
+        r.dx = __fadd_rn(__fadd_rn(__fmul_rn(m[0], s.x), __fmul_rn(m[1], s.y)), m[2]);
+        r.dy = __fadd_rn(__fadd_rn(__fmul_rn(m[4], s.x), __fmul_rn(m[5], s.y)), m[6]);
+        r.dz = __fadd_rn(__fadd_rn(__fmul_rn(m[8], s.x), __fmul_rn(m[9], s.y)), m[10]);
         r.ox = m[3]; r.oy = m[7]; r.oz = m[11];          // rays.py:68
         r.near = a.near; r.far = a.far;                  // rays.py:26
-        const float n = norm3(r.dx, r.dy, r.dz);         // rays.py:24
-        r.vx = __fdiv_rn(r.dx, n); r.vy = __fdiv_rn(r.dy, n); r.vz = __fdiv_rn(r.dz, n);
+        if (VIEW) {
+            const float n = norm3(r.dx, r.dy, r.dz);     // rays.py:24
+            r.vx = __fdiv_rn(r.dx, n); r.vy = __fdiv_rn(r.dy, n); r.vz = __fdiv_rn(r.dz, n);
+        }
     }
     r.dnorm = norm3(r.dx, r.dy, r.dz);                   // model_utils.py:60
     return r;
 }
+
+__device__ __forceinline__ Ray load_ray(const RenderArgs& a, int64_t idx) { return make_ray<true>(a, seed_ray(a, idx)); }
 
 // handler.py:218: near*(1-t) + far*t, two products and one sum
 __device__ __forceinline__ float coarse_z(const Ray& r, float t, float omt) {

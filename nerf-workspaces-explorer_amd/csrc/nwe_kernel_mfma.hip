@@ -306,7 +306,9 @@ struct Walker {
     // Piece i of the chunk being streamed.  Pieces go in groups of four: one scalar base per group, the 1-KiB step inside
     // a group rides on the instruction offset, which advances the global source AND the LDS destination (nwe_selftest
     // report[6]).  i is a compile-time constant at every call site.
-    __device__ __forceinline__ void piece(int i) {
+    // tail_piece: the piece with which this wave's tail pieces would start if the chunk has exactly the caller's static
+    // piece count (NB - 2); it rewrites M0 (a no-op for the waves and chunks whose destination does not change there).
+    __device__ __forceinline__ void piece(int i, int tail_piece = -1) {
 #ifdef NWE_EXP_NODMA   // timing experiments only; a run-time test here would split every k-step into its own basic block
         return;
 #endif
@@ -316,12 +318,12 @@ struct Walker {
         if (!X3 && skip_lo && (i & 1)) return;
         const uint8_t* src = blk_src + (size_t)(i >> 2) * (4 * kTileBytes);
         // the last two pieces of a long chunk (wave 3: n-2, n-1) go to the chunk's tail slot: a scalar select, no branch
-        const uint32_t base = (X3 && i >= tail_first) ? blk_dst_tail : blk_dst;
+        // (a long chunk has >= 8 pieces per wave, so only pieces 6.. can be tail pieces: no select in front of the others)
+        const uint32_t base = (X3 && i >= 6 && i >= tail_first) ? blk_dst_tail : blk_dst;
         const uint32_t dst = base + (i >> 2) * (4 * kTileBytes);
-        // M0 is written by the first piece of a group and by pieces 6 and 7, one of which is the first tail piece of an
-        // 8- or 9-piece quarter (a 10-piece quarter's first tail piece, 8, opens a group anyway); where neither is, the
-        // write repeats the value M0 already has.
-        const bool set_m0 = (i & 3) == 0 || (X3 && (i == 6 || i == 7));
+        // M0 is written by the first piece of a group and by the piece the tail would start with (6 of an 8-piece quarter, 7
+        // of a 9-piece one; the first tail piece of a 10-piece quarter, 8, opens a group anyway, and so does 8 of 9).
+        const bool set_m0 = (i & 3) == 0 || (X3 && i == tail_piece);
 #define NWE_GLDS(OFF) asm volatile("global_load_lds_dwordx4 %0, %1 offset:" #OFF :: "v"(lane_off), "s"(src) : "memory")
 #define NWE_GLDS_M0(OFF) asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:" #OFF \
                                       :: "v"(lane_off), "s"(src), "s"(dst) : "memory")
@@ -417,6 +419,7 @@ __device__ __forceinline__ void tile_mma(WalkerT& wk, Frags& F, int lane, bool u
     for (int g = 0; g < 4; ++g) cur.bias[g] = bp[2 * g + h];
     __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
     constexpr bool LONG_TILE = X3 && NQ >= 16;   // the (hi, lo) tiles of the last k-step live in the chunk's tail slot (Walker)
+    constexpr int S_LONG_PIECES = 8;             // Shape::LONG_PIECES: a chunk of >= 8 pieces per wave is a long one
     const char* cbase = wk.cur() + lane * 16;
     const char* nbase = wk.next() + lane * 16;
     const char* tbase = wk.tail() + lane * 16;
@@ -482,7 +485,7 @@ __device__ __forceinline__ void tile_mma(WalkerT& wk, Frags& F, int lane, bool u
             if constexpr (q < QSYNC && DP::TOT > 0) {
 #pragma unroll
                 for (int j = DP::lo(q); j < DP::lo(q + 1); ++j) {
-                    if (j < DP::REST) wk.piece(PD + j);
+                    if (j < DP::REST) wk.piece(PD + j, NB >= S_LONG_PIECES ? NB - 2 : -1);
                     else if (extraB) wk.piece(NB + j - DP::REST);
                 }
             }
@@ -669,8 +672,8 @@ __device__ __forceinline__ void view_tiles(WalkerT& wk, Frags& F, int lane, cons
 // is the feature layer without ReLU; alpha reads B, the view layer A); kept selectable for comparison.
 // On entry chunks 0 and 1 of the stream are visible / in flight and F holds the first PD k-steps of chunk 0.
 template <int W, int D, int SKIP, bool X3, bool FOLD, class WalkerT>
-__device__ __forceinline__ void mlp_eval(WalkerT& wk, Frags& F, int lane, float inv_scale, h8* Ghi, h8* Glo, const h8* GDhi,
-                                         const h8* GDlo, float& o_r, float& o_g, float& o_b, float& o_s) {
+__device__ __forceinline__ void mlp_eval(WalkerT& wk, Frags& F, int lane, float inv_scale, h8* Ghi, h8* Glo, const char* gd_lds,
+                                         float& o_r, float& o_g, float& o_b, float& o_s) {
     using S = Shape<W, D>;
     static_assert(D % 2 == 0, "trunk depth must be even");
     static_assert(SKIP < 0 || SKIP % 2 == 0, "skip layer index must be even");
@@ -684,25 +687,38 @@ __device__ __forceinline__ void mlp_eval(WalkerT& wk, Frags& F, int lane, float 
     layer<S::NT, 0, S::KG, X3, false, S::N_H, true>(wk, F, lane, false, SKIP_PAIR == 0, nullptr, nullptr, Ghi, Glo, Ahi, Alo, P0, P1,
                                                     inv_scale, 0.f, 0.f);
 #pragma unroll 1
-    for (int pair = 0; pair < NPAIR; ++pair) {
+    for (int pair = 0; pair < (FOLD ? NPAIR - 1 : NPAIR); ++pair) {
         const bool use_g = pair == SKIP_PAIR;
         const bool last = pair == NPAIR - 1;
         // first of pair: (gamma +) A -> B, ReLU.  Its first tile finishes the pending last tile of A (ReLU: the
-        // producer is layer 0 or a non-final second-of-pair layer).  FOLD: the last pair has only this layer; behind it
-        // come the alpha tile (a chunk of N_H pieces like a trunk layer's) and the view layer, whose chunk size the last
-        // tile needs for the head of chunk T+2.
+        // producer is layer 0 or a non-final second-of-pair layer).
         layer<S::NT, S::KG, S::KH, X3, true, S::N_H, false>(wk, F, lane, use_g, false, Ghi, Glo, Ahi, Alo, Bhi, Blo, P0, P1, inv_scale,
-                                                            0.f, 0.f, (FOLD && last) ? S::N_V : -1);
-        if (FOLD && last) break;
+                                                            0.f, 0.f);
         // second of pair: B -> A; !FOLD: the last pair's second layer is _feature_linear (no ReLU, nerf_model.py:64).
         // After it comes the next pair's first layer (skip: 2 more pieces) or the alpha tile and then the view layer.
         layer<S::NT, 0, S::KH, X3, true, S::N_H, false>(wk, F, lane, false, !last && pair + 1 == SKIP_PAIR, nullptr, nullptr, Bhi, Blo,
                                                         Ahi, Alo, P0, P1, inv_scale, 0.f, (!FOLD && last) ? -INFINITY : 0.f,
                                                         (!FOLD && last) ? S::N_V : -1);
     }
+    if constexpr (FOLD) {
+        // FOLD: the last trunk layer stands alone (A -> B); behind it come the alpha tile (a chunk of N_H pieces like a trunk
+        // layer's) and the view layer, whose chunk size the last tile needs for the head of chunk T+2.
+        constexpr bool G_LAST = SKIP_PAIR == NPAIR - 1;
+        layer<S::NT, G_LAST ? S::KG : 0, S::KH, X3, true, S::N_H, false>(wk, F, lane, G_LAST, false, Ghi, Glo, Ahi, Alo, Bhi, Blo, P0, P1,
+                                                                         inv_scale, 0.f, 0.f, S::N_V);
+    }
     constexpr int L = 2 * S::NT - 2;
     constexpr int LV = 2 * S::NTV - 2;
     static_assert((S::NTV * (S::KH + S::KD)) % (PD + 1) == 0, "the view tiles must restore the ring phase");
+    // gamma(d) is per-ray, used by the view layer only: it waits in LDS (this lane's 16 bytes of each fragment tile) instead
+    // of holding 16 registers through the trunk.  Read behind the trunk's last barrier, long before the view tiles' k-steps
+    // KH.. need it; older than the fragment reads the tile barriers leave in flight.
+    h8 GDhi[S::KD], GDlo[S::KD];
+#pragma unroll
+    for (int k = 0; k < S::KD; ++k) {
+        GDhi[k] = *reinterpret_cast<const h8*>(gd_lds + (2 * k) * kTileBytes);
+        if (X3) GDlo[k] = *reinterpret_cast<const h8*>(gd_lds + (2 * k + 1) * kTileBytes);
+    }
     if constexpr (FOLD) {
         // _alpha_linear on B = h (nerf_model.py:63); its first k-steps overlap the epilogue of the last trunk tile (P1),
         // whose outputs are the last two k-steps of B itself (ReLU).  Rows 0 and 4 of the alpha tile hold the output row.
@@ -749,9 +765,10 @@ struct Smem {
     static constexpr int WOFF = BOFF + 2 * BIAS_BYTES;                               // per-wave coarse weights / cdf
     static constexpr int TOFF = WOFF + WBYTES;                                       // t, 1-t, u tables
     static constexpr int XOFF = TOFF + (2 * kMaxSamples + kMaxImportance) * 4;         // sample-split mode: shaded samples, 2 buffers
-    static constexpr int LOFF = XOFF + 2 * kWaves * kRaysPerWave * 16;               // three tail slots of two tiles (Walker)
-    static constexpr int TOTAL = LOFF + 3 * 2 * kTileBytes;
-    static_assert(XOFF % 16 == 0 && LOFF % 16 == 0 && TOTAL <= 160 * 1024, "LDS budget");
+    static constexpr int LOFF = XOFF + (SPLIT ? 2 * kWaves * kRaysPerWave * 16 : 0);   // three tail slots of two tiles (Walker)
+    static constexpr int GOFF = LOFF + 3 * 2 * kTileBytes;                           // gamma(d) fragments, (hi, lo) per k-step and wave
+    static constexpr int TOTAL = GOFF + kWaves * 2 * S::KD * kTileBytes;
+    static_assert(XOFF % 16 == 0 && LOFF % 16 == 0 && GOFF % 16 == 0 && TOTAL <= 160 * 1024, "LDS budget");
 };
 
 // Two work decompositions, same arithmetic in the same order (results are bit-identical):
@@ -761,8 +778,28 @@ struct Smem {
 //                  sampling for all samples (a few dozen VALU ops per sample, redundantly).  The scheduling unit is a
 //                  quarter of the rays and a quarter of the iterations: a 320x240 frame fills the last round of
 //                  workgroups 17 % better, a 64x64 frame runs 3x faster; launch_t() picks per launch.
-template <int W, int D, int SKIP, bool X3, bool SPLIT, bool FOLD>
-__global__ void __launch_bounds__(256) render_mfma_kernel(RenderArgs a, NetMfma nc, NetMfma nf) {
+// What a plain frame does not use: everything but rgb / depth / acc / flags of pinhole views - the coarse-pass and
+// diagnostic outputs, raw network outputs, sample depths, coarse weights, the test hooks, the training-mode tables,
+// precomputed rays.  A launch without any of them takes the LEAN instantiation, in which they are compile-time null: their
+// ~40 pointers otherwise sit in (and spill from) the scalar registers of a kernel that has none to spare - 4.4 GB of
+// scratch writes per 800x800 frame before this split (profiles/r02_pmc_summary.txt).
+__host__ __device__ inline bool is_lean(const RenderArgs& a) {
+    const nwe_outputs& o = a.out;
+    return !o.raw_coarse && !o.raw_fine && !o.z_fine && !o.weights_coarse && !o.disp && !o.z_std && !o.rgb_coarse && !o.depth_coarse &&
+           !o.acc_coarse && !o.disp_coarse && !o.sample_cond && !o.sample_amp && !o.sample_switch && !a.z_fine_in && !a.raw_in_c &&
+           !a.raw_in_f && !a.w_in && !a.t_rand && !a.noise_c && !a.noise_f && !a.u_rand && !a.stamps && !a.rays;
+}
+
+template <int W, int D, int SKIP, bool X3, bool SPLIT, bool FOLD, bool LEAN>
+__global__ void __launch_bounds__(256) render_mfma_kernel(RenderArgs a_in, NetMfma nc, NetMfma nf) {
+    RenderArgs a = a_in;
+    if constexpr (LEAN) {
+        a.out.raw_coarse = a.out.raw_fine = a.out.z_fine = a.out.weights_coarse = nullptr;
+        a.out.disp = a.out.z_std = a.out.rgb_coarse = a.out.depth_coarse = a.out.acc_coarse = a.out.disp_coarse = nullptr;
+        a.out.sample_cond = a.out.sample_amp = a.out.sample_switch = nullptr;
+        a.z_fine_in = a.raw_in_c = a.raw_in_f = a.w_in = a.t_rand = a.noise_c = a.noise_f = a.u_rand = nullptr;
+        a.stamps = nullptr; a.rays = nullptr;
+    }
     using S = Shape<W, D>;
     using SM = Smem<W, D, SPLIT>;
     __shared__ __attribute__((aligned(16))) char smem[SM::TOTAL];
@@ -792,16 +829,33 @@ __global__ void __launch_bounds__(256) render_mfma_kernel(RenderArgs a, NetMfma 
     // lanes of a ragged last packet, which compute along and store nothing.  64-bit only where an offset is formed.
     const int row = (int)(ridx64 < a.n_rays ? ridx64 : a.n_rays - 1);
     const int64_t ridx = row, rclamp = row;
-    const Ray ray = load_ray(a, rclamp);
+    // The ray is kept as its three-register seed and expanded at the top of every sample iteration (bit-identical by
+    // construction): nothing of it but |d| stays in registers across an MLP evaluation.  The empty asm hides the seed from
+    // loop-invariant code motion, which would otherwise hoist the expansion and spill its results.
+    const RaySeed seed = seed_ray(a, rclamp);
+    auto fresh_ray = [&]() __attribute__((always_inline)) {
+        RaySeed sd = seed;
+        asm volatile("" : "+v"(sd.pose), "+v"(sd.x), "+v"(sd.y));
+        return make_ray<false>(a, sd);
+    };
 
     Walker<S::CHUNK_BYTES, X3> wk;
     wk.buf0 = smem; wk.lds_chunks = (uint32_t)(uintptr_t)(LDS_AS char*)smem;
     wk.tail0 = smem + SM::LOFF; wk.lds_tail = wk.lds_chunks + SM::LOFF; wk.t3 = 0;
     wk.b = 0; wk.wave = wave; wk.lane_off = lane * 16;
 
-    // gamma(d): once per ray (model_utils.py:23-25 re-embeds the same direction for every sample)
-    h8 GDhi[S::KD], GDlo[S::KD];
-    encode<2, S::KD, X3>(ray.vx, ray.vy, ray.vz, half, GDhi, GDlo);
+    // gamma(d): once per ray (model_utils.py:23-25 re-embeds the same direction for every sample), parked in LDS
+    char* gd_lds = smem + SM::GOFF + wave * (2 * S::KD * kTileBytes) + lane * 16;
+    {
+        const Ray rv = make_ray<true>(a, seed);
+        h8 GDhi[S::KD], GDlo[S::KD];
+        encode<2, S::KD, X3>(rv.vx, rv.vy, rv.vz, half, GDhi, GDlo);
+#pragma unroll
+        for (int k = 0; k < S::KD; ++k) {
+            *reinterpret_cast<h8*>(gd_lds + (2 * k) * kTileBytes) = GDhi[k];
+            *reinterpret_cast<h8*>(gd_lds + (2 * k + 1) * kTileBytes) = GDlo[k];
+        }
+    }
 
     FineSampler fs;
     // coarse weights, then the cdf: one buffer per wave (= per packet), or ONE for the workgroup's single packet (SPLIT), which
@@ -834,24 +888,27 @@ __global__ void __launch_bounds__(256) render_mfma_kernel(RenderArgs a, NetMfma 
         if constexpr (SPLIT) {
             // depths are produced strictly in order: zq[0..3] = this iteration's four samples, zq[4] = the first of the next
             int produced = 0;
-            auto gen = [&]() -> float {
+            auto gen = [&](const Ray& ray) -> float {
                 const int i = produced++;
                 if (i >= Stot) return 0.f;
                 if (pass == 0) return fs.cd.z(ray, i);
                 return a.z_fine_in ? a.z_fine_in[rclamp * Stot + i] : fs.next(ray);
             };
-            if (pass == 1) {
-                if (wc_writer) fs.build_cdf();     // in place: one wave, then everyone reads
-                __syncthreads();
-                fs.start(ray);
-                if (wants_survey(a.out)) {
-                    const SampleSurvey sv = fs.survey(ray);
-                    if (live) flags |= store_survey(a.out, ridx, sv);
-                }
-            }
             float zq[5], zp[4];
+            {
+                const Ray ray = fresh_ray();
+                if (pass == 1) {
+                    if (wc_writer) fs.build_cdf();     // in place: one wave, then everyone reads
+                    __syncthreads();
+                    fs.start(ray);
+                    if (wants_survey(a.out)) {
+                        const SampleSurvey sv = fs.survey(ray);
+                        if (live) flags |= store_survey(a.out, ridx, sv);
+                    }
+                }
 #pragma unroll
-            for (int k = 0; k < 5; ++k) zq[k] = gen();
+                for (int k = 0; k < 5; ++k) zq[k] = gen(ray);
+            }
             float4* xch = reinterpret_cast<float4*>(smem + SM::XOFF);
             const int n_it = (Stot + 3) / 4;
             // composite the (up to four) samples of iteration `it`, shaded by the four waves, in sample order
@@ -882,6 +939,7 @@ __global__ void __launch_bounds__(256) render_mfma_kernel(RenderArgs a, NetMfma 
 #pragma unroll
                     for (int i = 0; i < S::N_L0; ++i) wk.piece(i);
                 }
+                const Ray ray = fresh_ray();
                 const int s_own = 4 * it + wave;
                 const bool own_valid = s_own < Stot;
                 float z_own = zq[0], z_nxt = zq[1];
@@ -890,7 +948,7 @@ __global__ void __launch_bounds__(256) render_mfma_kernel(RenderArgs a, NetMfma 
                 if (wave == 3) { z_own = zq[3]; z_nxt = zq[4]; }
                 float nz[4];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) nz[k] = gen();
+                for (int k = 0; k < 4; ++k) nz[k] = gen(ray);
                 float rr, rg, rb, rs;
                 if (raw_in) {
                     __syncthreads();             // publishes the previous iteration's shaded samples
@@ -923,7 +981,7 @@ __global__ void __launch_bounds__(256) render_mfma_kernel(RenderArgs a, NetMfma 
                 wk.st_t0 = t2;
                 st_sync += t2 - t1;
 #endif
-                mlp_eval<W, D, SKIP, X3, FOLD>(wk, F, lane, net.inv_scale, Ghi, Glo, GDhi, GDlo, rr, rg, rb, rs);
+                mlp_eval<W, D, SKIP, X3, FOLD>(wk, F, lane, net.inv_scale, Ghi, Glo, gd_lds, rr, rg, rb, rs);
 #ifdef NWE_STAMPS
                 st_mlp += __builtin_amdgcn_s_memtime() - t2;
 #endif
@@ -955,14 +1013,17 @@ __global__ void __launch_bounds__(256) render_mfma_kernel(RenderArgs a, NetMfma 
             __syncthreads();   // the exchange buffers are free again for the next pass
         } else {
             float z_cur, z_next = 0.f;
-            if (pass == 0) z_cur = fs.cd.z(ray, 0);
-            else {
-                fs.prepare(ray);
-                if (wants_survey(a.out)) {
-                    const SampleSurvey sv = fs.survey(ray);
-                    if (live) flags |= store_survey(a.out, ridx, sv);
+            {
+                const Ray ray = fresh_ray();
+                if (pass == 0) z_cur = fs.cd.z(ray, 0);
+                else {
+                    fs.prepare(ray);
+                    if (wants_survey(a.out)) {
+                        const SampleSurvey sv = fs.survey(ray);
+                        if (live) flags |= store_survey(a.out, ridx, sv);
+                    }
+                    z_cur = a.z_fine_in ? a.z_fine_in[rclamp * Stot] : fs.next(ray);
                 }
-                z_cur = a.z_fine_in ? a.z_fine_in[rclamp * Stot] : fs.next(ray);
             }
             for (int s = 0; s < Stot; ++s) {
     #ifdef NWE_STAMPS
@@ -978,6 +1039,7 @@ __global__ void __launch_bounds__(256) render_mfma_kernel(RenderArgs a, NetMfma 
     #pragma unroll
                     for (int i = 0; i < S::N_L0; ++i) wk.piece(i);
                 }
+                const Ray ray = fresh_ray();
                 if (s + 1 < Stot) {
                     if (pass == 0) z_next = fs.cd.z(ray, s + 1);
                     else z_next = a.z_fine_in ? a.z_fine_in[rclamp * Stot + s + 1] : fs.next(ray);
@@ -1008,7 +1070,7 @@ __global__ void __launch_bounds__(256) render_mfma_kernel(RenderArgs a, NetMfma 
                 wk.st_t0 = t2;
                 st_sync += t2 - t1;
     #endif
-                mlp_eval<W, D, SKIP, X3, FOLD>(wk, F, lane, net.inv_scale, Ghi, Glo, GDhi, GDlo, rr, rg, rb, rs);
+                mlp_eval<W, D, SKIP, X3, FOLD>(wk, F, lane, net.inv_scale, Ghi, Glo, gd_lds, rr, rg, rb, rs);
     #ifdef NWE_STAMPS
                 st_mlp += __builtin_amdgcn_s_memtime() - t2;
     #endif
@@ -1048,6 +1110,10 @@ __global__ void __launch_bounds__(256) render_mfma_kernel(RenderArgs a, NetMfma 
 #endif
 }
 
+#ifdef NWE_ONE_KERNEL   // register-pressure experiments: `make one` compiles just the headline instantiation to assembly
+template __global__ void render_mfma_kernel<256, 8, 4, true, false, NWE_ONE_KERNEL, true>(RenderArgs, NetMfma, NetMfma);
+}  // namespace nwe
+#else
 // Instantiated shapes: width 128 or 256, even depth 4 / 6 / 8 with the reference's skip connection (after layer 4 where
 // that layer exists and feeds another trunk layer, nerf_model.py:13,58-59; none for depth 4), 63/27-wide encodings.
 // The unfolded formulation (!FOLD) exists for the two BASELINE shapes only.
@@ -1067,13 +1133,17 @@ static void launch_one(RenderArgs a, const NetMfma& nc, const NetMfma& nf, bool 
     a.ray_first = ray_first;
     const int64_t per_wg = split ? kRaysPerWave : kWaves * kRaysPerWave;
     const unsigned blocks = (unsigned)((rays + per_wg - 1) / per_wg);
+#define NWE_LAUNCH(X3_, SPLIT_, LEAN_) \
+    hipLaunchKernelGGL((render_mfma_kernel<W, D, SKIP, X3_, SPLIT_, FOLD, LEAN_>), dim3(blocks), dim3(256), 0, stream, a, nc, nf)
+    const bool lean = is_lean(a);
     if (three_pass) {
-        if (split) hipLaunchKernelGGL((render_mfma_kernel<W, D, SKIP, true, true, FOLD>), dim3(blocks), dim3(256), 0, stream, a, nc, nf);
-        else hipLaunchKernelGGL((render_mfma_kernel<W, D, SKIP, true, false, FOLD>), dim3(blocks), dim3(256), 0, stream, a, nc, nf);
+        if (split) { if (lean) NWE_LAUNCH(true, true, true); else NWE_LAUNCH(true, true, false); }
+        else       { if (lean) NWE_LAUNCH(true, false, true); else NWE_LAUNCH(true, false, false); }
     } else {
-        if (split) hipLaunchKernelGGL((render_mfma_kernel<W, D, SKIP, false, true, FOLD>), dim3(blocks), dim3(256), 0, stream, a, nc, nf);
-        else hipLaunchKernelGGL((render_mfma_kernel<W, D, SKIP, false, false, FOLD>), dim3(blocks), dim3(256), 0, stream, a, nc, nf);
+        if (split) { if (lean) NWE_LAUNCH(false, true, true); else NWE_LAUNCH(false, true, false); }
+        else       { if (lean) NWE_LAUNCH(false, false, true); else NWE_LAUNCH(false, false, false); }
     }
+#undef NWE_LAUNCH
 }
 
 template <int W, int D, int SKIP, bool FOLD>
@@ -1128,3 +1198,4 @@ bool launch_render_mfma(const RenderArgs& a, const NetMfma& nc, const NetMfma& n
 }
 
 }  // namespace nwe
+#endif

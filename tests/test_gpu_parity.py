@@ -972,3 +972,27 @@ def test_folded_feature_layer_against_the_unfolded_formulation():
     d_depth = (res[True]["depth"] - res[False]["depth"]).abs().max().item()
     print(f"folded vs unfolded, 640 000 rays: rgb {d_rgb:.2e}, depth {d_depth:.2e}, raw (1600 rays) {d_raw:.2e}")
     assert d_raw <= 2e-6 and d_rgb <= 1e-5 and d_depth / FAR <= 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", [0, 1])
+def test_lean_and_full_kernel_instantiations_are_bit_identical(r_c3, mode):
+    """A frame that asks for rgb / depth / acc only runs the LEAN instantiation of the MFMA kernel (every other input and
+    output compile-time null, no register spills); any further output, a test hook or precomputed rays select the full
+    one.  Same arithmetic: identical bits, both work decompositions, both MFMA modes."""
+    fx, fy, cx, cy = O.intrinsics(40, 52)
+    pose = O.camera_pose((0.0, -0.5, -0.77, 0.0, -90.0, 0.0), (0, 0, 0, -30.0, 0.0, 0.0))[0].numpy()
+    kw = dict(fx=fx, fy=fy, cx=cx, cy=cy, near=0.1, far=10.0)
+    r_c3.debug_set_decomposition(mode)
+    try:
+        for precision in ("f16x3", "f16x1"):
+            lean = r_c3.render(pose, 40, 52, precision=precision, outputs=("rgb", "depth", "acc"), **kw)
+            full = r_c3.render(pose, 40, 52, precision=precision, outputs=("rgb", "depth", "acc", "disp", "z_std", "rgb_coarse", "raw_fine",
+                                                                          "weights_coarse", "sample_amp"), **kw)
+            rays = r_c3.create_rays(pose, 40, 52, **kw)
+            via_rays = r_c3.render_rays(rays, precision=precision, outputs=("rgb", "depth", "acc"))
+            for k in ("rgb", "depth", "acc"):
+                assert torch.equal(lean[k], full[k]) and torch.equal(lean[k], via_rays[k]), (precision, k)
+            assert int(lean["flags"].item()) & 0x7 == int(full["flags"].item()) & 0x7
+    finally:
+        r_c3.debug_set_decomposition(-1)
