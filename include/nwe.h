@@ -213,6 +213,9 @@ int nwe_set_train_tables(nwe_ctx *ctx, const float *t_rand_dev, const float *noi
  * workgroups as packets and the ragged last round sample-split in a second launch; mode 0 / 1 / 2 forces a plan, -1
  * restores the automatic choice. */
 int nwe_debug_set_decomposition(nwe_ctx *ctx, int mode);
+/* The plan the most recent MFMA launch of this context took (0 packets / 1 sample split / 2 packets + split rest), -1 if
+ * none yet: lets a test check the launcher's choice without timing anything. */
+int nwe_debug_last_plan(const nwe_ctx *ctx);
 
 /* Diagnostic builds only (make -C csrc stamps): DEVICE buffer of 8 uint64 per wave that a -DNWE_STAMPS build of the MFMA
  * kernel fills with s_memtime cycle sums (tools/stamp_run.py); the product build never touches it.  NULL switches it off. */

@@ -66,6 +66,7 @@ struct nwe_ctx {
     int flag_parts_cap = 0;
     int white_bkgd = 0;
     int decomposition = -1;   // nwe_debug_set_decomposition
+    int last_plan = -1;       // nwe_debug_last_plan
     unsigned long long* stamps = nullptr;   // nwe_debug_set_stamps
     const float *trn_t = nullptr, *trn_nc = nullptr, *trn_nf = nullptr, *trn_u = nullptr;   // nwe_set_train_tables, one call
     std::string err;
@@ -86,7 +87,7 @@ int fail(nwe_ctx* c, int code, const std::string& msg) {
     } while (0)
 
 // ---------------------------------------------------------------------------------------------
-// packing for the MFMA kernel.  Must mirror nwe_kernel_mfma.hip (encode(), split_tile(), tile_mma()).
+// packing for the MFMA kernel.  Must mirror nwe_mfma_kernels.h (encode(), split_tile(), tile_mma()).
 // ---------------------------------------------------------------------------------------------
 
 // Column of gamma(v) (embedding.py:24-48 order: identity(3), then per band sin(3), cos(3)) that lane half h
@@ -328,7 +329,8 @@ int launch(nwe_ctx* ctx, nwe_ctx::Slot& slot, RenderArgs& a, int precision, void
     if (precision == NWE_PREC_F32) {
         launch_render_f32(a, ctx->net[0].f32, ctx->net[ctx->ni > 0 ? 1 : 0].f32, stream);
     } else {
-        if (!launch_render_mfma(a, ctx->net[0].mf, ctx->net[ctx->ni > 0 ? 1 : 0].mf, precision == NWE_PREC_F16X3, ctx->decomposition, stream))
+        if (!launch_render_mfma(a, ctx->net[0].mf, ctx->net[ctx->ni > 0 ? 1 : 0].mf, precision == NWE_PREC_F16X3, ctx->decomposition, stream,
+                                &ctx->last_plan))
             return fail(ctx, NWE_ERR_UNSUPPORTED, "coarse and fine networks must have the same shape for the MFMA kernel");
     }
     HIPCHK(ctx, hipGetLastError());
@@ -690,6 +692,8 @@ int nwe_debug_set_decomposition(nwe_ctx* c, int mode) {
     c->decomposition = mode;
     return NWE_OK;
 }
+
+int nwe_debug_last_plan(const nwe_ctx* c) { return c ? c->last_plan : -1; }
 
 int nwe_debug_set_stamps(nwe_ctx* c, unsigned long long* per_wave_dev) {
     if (!c) return NWE_ERR_INVALID;

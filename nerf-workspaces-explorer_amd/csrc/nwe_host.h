@@ -37,7 +37,9 @@ bool mfma_supported(int D, int W, int in_xyz, int in_dir, int skip, bool folded)
 // returns false if the shape has no instantiation.  decomposition: -1 = pick by frame size, 0 = four ray packets per
 // workgroup, 1 = one packet per workgroup with its samples dealt to the four waves, 2 = full rounds as 0 and the ragged
 // last round as 1 in a second launch (bit-identical results)
-bool launch_render_mfma(const RenderArgs& a, const NetMfma& nc, const NetMfma& nf, bool three_pass, int decomposition, hipStream_t stream);
+// *plan_out (may be null) receives the plan taken (0 / 1 / 2 as above)
+bool launch_render_mfma(const RenderArgs& a, const NetMfma& nc, const NetMfma& nf, bool three_pass, int decomposition, hipStream_t stream,
+                        int* plan_out);
 
 constexpr int kTileBytes = 1024;
 int mfma_max_samples();      // n_samples the MFMA kernel's per-wave LDS buffers are sized for

@@ -1,0 +1,6 @@
+// Instantiations of the MFMA render kernel, part a (see nwe_kernel_mfma.hip).
+#include "nwe_mfma_kernels.h"
+
+namespace nwe {
+template bool launch_t<256, 8, 4, true>(const RenderArgs&, const NetMfma&, const NetMfma&, bool, int, hipStream_t, int*);
+}  // namespace nwe

@@ -1,0 +1,7 @@
+// Instantiations of the MFMA render kernel, part c (see nwe_kernel_mfma.hip).
+#include "nwe_mfma_kernels.h"
+
+namespace nwe {
+template bool launch_t<256, 6, 4, true>(const RenderArgs&, const NetMfma&, const NetMfma&, bool, int, hipStream_t, int*);
+template bool launch_t<128, 4, -1, false>(const RenderArgs&, const NetMfma&, const NetMfma&, bool, int, hipStream_t, int*);
+}  // namespace nwe

@@ -251,6 +251,10 @@ class Renderer:
         ragged last round, -1 = automatic (bit-identical results)."""
         self._check(self._lib.nwe_debug_set_decomposition(self._ctx, int(mode)), "nwe_debug_set_decomposition")
 
+    def debug_last_plan(self) -> int:
+        """Test hook: the decomposition the last MFMA launch took (0 packets, 1 sample split, 2 packets + split rest)."""
+        return int(self._lib.nwe_debug_last_plan(self._ctx))
+
     def set_white_background(self, on: bool) -> None:
         """rendering.white_background (model_utils.py:97-98): rgb += 1 - acc on every rgb output."""
         self._check(self._lib.nwe_set_white_background(self._ctx, 1 if on else 0), "nwe_set_white_background")

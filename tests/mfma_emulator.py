@@ -1,4 +1,4 @@
-"""numpy emulation of how nwe_kernel_mfma.hip consumes the packed weight stream.
+"""numpy emulation of how nwe_mfma_kernels.h (mlp_eval) consumes the packed weight stream.
 
 It replays mlp_eval() with the documented lane maps of v_mfma_f32_32x32x16_f16 (A: lane (i,h) holds
 A[i][8h+j]; B: lane (n,h) holds B[8h+j][n]; D: lane (n,h) register r holds D[(r&3)+8(r>>2)+4h][n]) on the

@@ -3,6 +3,7 @@
 import ctypes as C
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -87,30 +88,14 @@ def test_stream_layout_properties():
     assert np.array_equal(bias[-1][:3], sd["_rgb_linear.bias"]) and np.array_equal(bias[-1][4:7], sd["_rgb_linear.bias"])
 
 
-def test_kernel_owns_m0(tmp_path):
-    """nwe_kernel_mfma.hip keeps the LDS-DMA destination in M0 across statements (one write per group of four pieces),
-    which is sound only while hipcc emits no M0 use of its own in that kernel: disassemble the SHIPPED library and check
-    that every instruction touching m0 in the render kernels' code object is one of ours (s_mov_b32 m0, <scalar register>)."""
-    import shutil
-    import subprocess
-    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
-    if not os.path.exists(objdump):
-        pytest.skip("llvm-objdump not available")
-    lib = tmp_path / "libnwe_hip.so"
-    shutil.copy(_lib.LIB_PATH, lib)
-    subprocess.run([objdump, "--offloading", lib.name], cwd=tmp_path, check=True, capture_output=True)
-    checked = 0
-    for co in sorted(tmp_path.glob("*.hipv4-amdgcn-amd-amdhsa--gfx950")):
-        dis = subprocess.run([objdump, "-d", co.name], cwd=tmp_path, check=True, capture_output=True, text=True).stdout
-        if "render_mfma_kernel" not in dis:
-            continue
-        body = dis[dis.index("render_mfma_kernel"):]
-        for line in body.splitlines():
-            ins = line.split("//")[0].strip()
-            if re.search(r"\bm0\b", ins):
-                assert re.fullmatch(r"s_mov_b32 m0, (s\d+|vcc_lo|vcc_hi)", ins), f"unexpected M0 use in the MFMA kernel: {ins!r}"
-                checked += 1
-    assert checked > 0, "no LDS-DMA destination writes found: is this the right code object?"
+def test_kernel_owns_m0():
+    """nwe_mfma_kernels.h keeps the LDS-DMA destination in M0 across statements (one write per group of pieces), which is
+    sound only while hipcc emits no M0 use of its own in that kernel: tools/check_m0.py disassembles the SHIPPED library and
+    checks that every instruction touching m0 in the render kernels is one of ours.  A missing disassembler fails the
+    test (the same check runs in __graft_entry__.build(), so a library that breaks the invariant does not get built)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import check_m0
+    assert check_m0.check(_lib.LIB_PATH) > 1000
 
 
 def test_outputs_struct_guard_and_integration_stub_layout():

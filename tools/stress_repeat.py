@@ -1,5 +1,5 @@
 """Stress: N renders of the 800x800 bench frame, every output bit-compared with the first (race detector for the LDS
-double buffer / relaxed pre-barrier wait; see Walker::sync in csrc/nwe_kernel_mfma.hip)."""
+double buffer / relaxed pre-barrier wait; see Walker::sync in csrc/nwe_mfma_kernels.h)."""
 import os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
