@@ -118,6 +118,8 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--precision", default="f16x3", choices=["f16x3", "f16x1", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--in-process-probe", type=int, default=0, metavar="N",
+                    help="internal: render ONE frame through nwe_render_tiled on devices 0..N-1 from this process, print a JSON object, exit")
     ap.add_argument("--unfolded", action="store_true",
                     help="comparison only: evaluate _feature_linear as its own layer instead of folding it into the view layer at pack time")
     args = ap.parse_args()
@@ -127,15 +129,33 @@ def main() -> None:
     import nwe_amd
     from nwe_amd.dist import TileShardedRenderer
 
+    if args.in_process_probe:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        sd_c = nwe_amd.synthetic.make_state_dict(1000, 8, 256)
+        sd_f = nwe_amd.synthetic.make_state_dict(1001, 8, 256)
+        print(json.dumps(in_process_frame(args, sd_c, sd_f, sweep_pose(0, 1), args.in_process_probe, torch.cuda.device_count())), flush=True)
+        return
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC for RCCL; must be set before the first HIP call
+    # NWE_BENCH_BACKEND=gloo is a REHEARSAL switch for boxes with fewer GPUs than ranks (tests/test_gpu_dist.py runs two ranks
+    # on the one GPU of the test box, which RCCL does not allow): ranks share devices, the gather goes through the host.
+    backend = os.environ.get("NWE_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
+    host_group = None
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
+        host_group = dist.new_group(backend="gloo")      # a barrier that parks no kernel on the GPUs (see the end of main)
+    red_dev = "cuda" if backend == "nccl" else "cpu"
 
     sd_c = nwe_amd.synthetic.make_state_dict(1000, 8, 256)
     sd_f = nwe_amd.synthetic.make_state_dict(1001, 8, 256)
@@ -170,7 +190,7 @@ def main() -> None:
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
@@ -193,7 +213,7 @@ def main() -> None:
             tsr.render_frames(one, H, W)
             skm.append(h.renderer.last_kernel_ms())
         fence()
-        st = torch.tensor([time.perf_counter() - t1, float(np.mean(skm))], dtype=torch.float64, device="cuda")
+        st = torch.tensor([time.perf_counter() - t1, float(np.mean(skm))], dtype=torch.float64, device=red_dev)
         dist.all_reduce(st, op=dist.ReduceOp.MAX)
         ms_frame = float(st[0].item()) / STRONG_STEPS * 1e3
         strong = {"workload": f"C4: ONE 800x800 frame as {world} row tiles ({H // world * W} rays per rank) + RCCL gather",
@@ -222,7 +242,7 @@ def main() -> None:
             "config": {"workload": "C3: 800x800 view, 64 coarse + 128 importance samples, 8x256 coarse + fine NeRF MLP, "
                                    "hfov 90, near 0.1 far 10, random-init weights (seeds 1000/1001)",
                        "frames_per_step": frames_per_step, "rays_per_step": rays_per_step,
-                       "parallelism": f"row-tile x{world}" + (" + RCCL gather" if world > 1 else "")},
+                       "parallelism": f"row-tile x{world}" + ((" + RCCL gather" if backend == "nccl" else f" + {backend} gather (REHEARSAL: ranks share devices)") if world > 1 else "")},
             "per_gpu_ray_samples_per_s": value / world,
             "rays_per_s": rays_per_step * args.steps / elapsed,
             "mlp_evals_per_s": rays_per_step * evals_per_ray * args.steps / elapsed,
@@ -243,7 +263,7 @@ def main() -> None:
         }
         if strong is not None:
             line["strong"] = strong
-            line["in_process"] = in_process_frame(args, sd_c, sd_f, poses[0], world, torch.cuda.device_count())
+            line["in_process"] = in_process_probe(args, world)
         if world == 1 and not args.no_cpu_baseline:
             rays, ref, dt, start, threads = cpu_baseline(sd_c, sd_f, poses[0])
             cpu_value = CPU_SAMPLE_RAYS * (NS + NI) / dt
@@ -275,7 +295,24 @@ def main() -> None:
                         "above 1e-4 is one whose sample depths moved, every ray sampled where the oracle sampled it is within 1e-4"}
         print(json.dumps(line), flush=True)
     if world > 1:
+        dist.barrier(group=host_group)      # ranks != 0 wait here, on the host, while rank 0's child renders on all devices
         dist.destroy_process_group()
+
+
+def in_process_probe(args, n):
+    """The in-process leg in a CHILD process of rank 0 (the other ranks idle on a host-side barrier meanwhile): a path that
+    has only ever run with all tiles on one GPU must not be able to take the headline line down with it."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--in-process-probe", str(n), "--precision", args.precision]
+    try:
+        env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK")}
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=env)
+        for ln in reversed(out.stdout.strip().splitlines()):
+            if ln.startswith("{"):
+                return json.loads(ln)
+        return {"error": f"probe exited {out.returncode} without a result", "stderr_tail": out.stderr[-400:]}
+    except Exception as exc:   # noqa: BLE001
+        return {"error": f"{type(exc).__name__}: {exc}"}
 
 
 def in_process_frame(args, sd_c, sd_f, pose, n, n_visible):
@@ -283,9 +320,12 @@ def in_process_frame(args, sd_c, sd_f, pose, n, n_visible):
     frame with hipMemcpyPeerAsync.  The other ranks are idle (behind the barrier) while this runs."""
     try:
         import nwe_amd
+        devices = list(range(n))
         if n_visible < n:
-            return {"skipped": f"{n_visible} devices visible to this process, {n} needed"}
-        hh = nwe_amd.NeRFReplicaInferenceHandler("office_tokyo", "synthetic", precision=args.precision, devices=list(range(n)))
+            if os.environ.get("NWE_BENCH_BACKEND", "nccl") == "nccl":
+                return {"skipped": f"{n_visible} devices visible to this process, {n} needed"}
+            devices = [i % n_visible for i in devices]      # rehearsal: several tiles per device, same code path
+        hh = nwe_amd.NeRFReplicaInferenceHandler("office_tokyo", "synthetic", precision=args.precision, devices=devices)
         hh.set_sampling(NS, NI)
         hh.initialize_models(state_dicts=(sd_c, sd_f))
         for _ in range(2):
@@ -296,7 +336,7 @@ def in_process_frame(args, sd_c, sd_f, pose, n, n_visible):
             out = hh.render_batch(pose[None], H, W)
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) / STRONG_STEPS * 1e3
-        return {"workload": f"ONE 800x800 frame as {n} row tiles on devices 0..{n - 1} from one process (nwe_render_tiled)",
+        return {"workload": f"ONE 800x800 frame as {n} row tiles on devices {devices} from one process (nwe_render_tiled)",
                 "ms_per_frame": ms, "tile_kernel_ms": hh.renderer.tile_kernel_ms(), "flags": int(out["flags"].item())}
     except Exception as exc:   # noqa: BLE001 - a diagnostic leg must not take the headline number down with it
         return {"error": f"{type(exc).__name__}: {exc}"}

@@ -55,3 +55,32 @@ def test_gather_tiles_device_branch_under_rccl():
         assert got["rgb"].is_cuda and torch.equal(got["rgb"], want["rgb"]) and torch.equal(got["depth"], want["depth"])
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_bench_multi_rank_line_rehearsal():
+    """bench.py's N > 1 branch end to end, as the driver launches it (torch.distributed.run, one rank per GPU), rehearsed
+    with two ranks on the ONE GPU of the test box: NWE_BENCH_BACKEND=gloo lets ranks share a device (RCCL does not).  Checks
+    the line's contract - whole-job value, weak scaling, `strong` (one frame N ways) and `in_process` (child process of rank
+    0 through nwe_render_tiled) - not its numbers."""
+    import json
+    import socket
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, NWE_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]                    # rank 0 prints ONE line
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["steps"] == 1 and d["config"]["frames_per_step"] == 2
+    assert d["value"] > 1e7 and abs(d["value"] - 2 * 640000 * 192 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+    assert d["strong"]["ms_per_frame"] > 0 and d["strong"]["kernel_ms_slowest_rank"] > 0
+    assert "error" not in d["in_process"] and "skipped" not in d["in_process"], d["in_process"]
+    assert d["in_process"]["ms_per_frame"] > 0 and len(d["in_process"]["tile_kernel_ms"]) == 2
+    assert "cpu_baseline" not in d                                 # rank 0 at N = 1 only
+    print("rehearsal line:", {k: d[k] for k in ("value", "ms_per_step")}, d["strong"]["ms_per_frame"], d["in_process"]["ms_per_frame"])
