@@ -48,7 +48,7 @@ def pinhole_intrinsics(H: int, W: int, hfov_deg: float = 90.0) -> Tuple[float, f
 
 class NeRFReplicaInferenceHandler:
 
-    def __init__(self, office_name: str, ckpt_path: str, device: int = 0, precision: str = "f16x3",
+    def __init__(self, office_name: str, ckpt_path: str, device: int = 0, precision: str = "auto",
                  devices: Optional[Sequence[int]] = None) -> None:
         """``devices`` (or the environment variable NWE_DEVICES, e.g. "0,1,2,3", for a caller that constructs the handler
         with the reference's two arguments, application/workspace.py:28-29): render every frame as row tiles on these
@@ -59,9 +59,13 @@ class NeRFReplicaInferenceHandler:
         if devices is None and os.environ.get("NWE_DEVICES"):
             devices = [int(d) for d in os.environ["NWE_DEVICES"].split(",") if d.strip() != ""]
         self._devices = list(devices) if devices else None
-        if precision not in _lib.PRECISIONS:
-            raise ValueError(f"precision must be one of {sorted(_lib.PRECISIONS)}")
+        # "auto": the fp32-grade MFMA mode (f16x3) where the network shape has an MFMA instantiation (every shape the
+        # reference's configs use), else the fp32 vector-ALU HIP kernel, with a notice - a legal YAML (say net_width 64) must
+        # render, slowly, rather than raise.  Decided in initialize_models(), when the shapes are known.
+        if precision != "auto" and precision not in _lib.PRECISIONS:
+            raise ValueError(f"precision must be 'auto' or one of {sorted(_lib.PRECISIONS)}")
         self._precision = precision
+        self._auto_precision = precision == "auto"
 
         cfg = Config.for_office(office_name)
         self._endpoint_feat = cfg.get_param(("experiment", "endpoint_feat"), bool, default=False)
@@ -118,6 +122,15 @@ class NeRFReplicaInferenceHandler:
             self._renderer.set_network(_lib.NET_FINE, fine)
         self._renderer.set_sampling(self._n_samples, self._n_importance)
         self._renderer.set_white_background(self._white_bkgd)                     # handler.py:57,231,253
+        if self._auto_precision:
+            nets = (_lib.NET_COARSE,) + ((_lib.NET_FINE,) if fine is not None else ())
+            mfma = all(self._renderer.mfma_supported(w) for w in nets)
+            if mfma and fine is not None and self._renderer.shapes[_lib.NET_COARSE] != self._renderer.shapes[_lib.NET_FINE]:
+                mfma = False                  # the fused MFMA kernel runs both passes with one instantiation
+            self._precision = "f16x3" if mfma else "f32"
+            if not mfma:
+                print(f"[nwe] network shape {self._renderer.shapes.get(_lib.NET_COARSE)} has no MFMA instantiation: rendering with the "
+                      "fp32 vector-ALU kernel (same results, ~25x slower)")
 
     def _need_renderer(self) -> Renderer:
         if self._renderer is None:

@@ -271,6 +271,10 @@ class Renderer:
     def last_kernel_ms(self) -> float:
         return float(self._lib.nwe_last_kernel_ms(self._ctx))
 
+    def mfma_supported(self, which: int) -> bool:
+        """True if network `which` has been packed for the MFMA kernel (its shape has an instantiation)."""
+        return int(self._lib.nwe_packed_bytes(self._ctx, which)) > 0
+
     def flops_per_eval(self, which: int) -> int:
         return int(self._lib.nwe_flops_per_eval(self._ctx, which))
 

@@ -49,7 +49,7 @@ def click_to_coordinates(office: str, rel_x: float, rel_y: float, hor_angle: flo
 
 
 class Workspace:
-    def __init__(self, name: str, model_path: Optional[str] = None, device: int = 0, precision: str = "f16x3",
+    def __init__(self, name: str, model_path: Optional[str] = None, device: int = 0, precision: str = "auto",
                  devices: Optional[Sequence[int]] = None) -> None:
         if name not in OFFICES:
             raise KeyError(f"unknown workspace {name!r}; known: {sorted(OFFICES)}")

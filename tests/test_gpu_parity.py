@@ -1018,3 +1018,25 @@ def test_lean_and_full_kernel_instantiations_are_bit_identical(r_c3, mode):
             assert int(lean["flags"].item()) & 0x7 == int(full["flags"].item()) & 0x7
     finally:
         r_c3.debug_set_decomposition(-1)
+
+
+@pytest.mark.gpu
+def test_handler_renders_any_legal_shape(capsys):
+    """The handler's default precision is "auto": the fp32-grade MFMA mode where the shape has an instantiation (8x256 as in
+    all four reference YAMLs; also 6-deep, 128-wide ...), else the fp32 vector-ALU HIP kernel with a notice - a legal YAML
+    (here net_width 64, net_depth 6) renders instead of raising.  Both against the live oracle."""
+    fx, fy, cx, cy = O.intrinsics(12, 16)
+    pose = O.camera_pose((0.0, -0.5, -0.77, 0.0, -90.0, 0.0), (0, 0, 0, -30.0, 0.0, 0.0))
+    rays = O.create_rays(pose, 12, 16, fx, fy, cx, cy, 0.1, 10.0)[0]
+    for (D, Wn, skips), want in (((6, 64, (4,)), "f32"), ((6, 256, (4,)), "f16x3"), ((8, 256, (4,)), "f16x3")):
+        sd_c = nwe_amd.synthetic.thin_fog(nwe_amd.synthetic.make_state_dict(31, D, Wn, skips=skips))
+        sd_f = nwe_amd.synthetic.make_state_dict(32, D, Wn, skips=skips)
+        h = nwe_amd.NeRFReplicaInferenceHandler("office_tokyo", "unused")
+        h.initialize_models(state_dicts=(sd_c, sd_f))
+        assert h._precision == want
+        got = h.render(pose[0].numpy(), 12, 16)["rgb"].reshape(-1, 3).cpu().numpy()
+        ref = O.render_rays(rays, _t(sd_c), _t(sd_f), O.RenderConfig())
+        ok = ref["raw_fine"][:, -1, 3].abs().numpy() > 1e-5
+        assert np.abs(got - ref["rgb_fine"].numpy())[ok].max() <= RGB_TOL, (D, Wn)
+        text = capsys.readouterr().out
+        assert ("no MFMA instantiation" in text) == (want == "f32")
