@@ -120,3 +120,15 @@ def test_outputs_struct_guard_and_integration_stub_layout():
     assert lib.nwe_render_rays(ctx, None, 0, 0, C.byref(o), None) == _lib.NWE_ERR_INVALID
     assert b"struct_bytes" in lib.nwe_last_error(ctx)
     lib.nwe_destroy(ctx)
+
+
+def test_header_is_usable_from_plain_c(tmp_path):
+    """include/nwe.h compiled as C99 by gcc, linked against the library, exercised on a host-only context
+    (tests/c/abi_smoke.c): the boundary is a C ABI, not a C++ one."""
+    import subprocess
+    exe = tmp_path / "abi_smoke"
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "c", "abi_smoke.c"),
+                    "-o", str(exe), "-L", libdir, "-lnwe_hip", "-lm", f"-Wl,-rpath,{libdir}"], check=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert out.returncode == 0 and "abi_smoke ok" in out.stdout, out.stderr

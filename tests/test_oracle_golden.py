@@ -118,6 +118,19 @@ def test_end_to_end_c3_subset_small(golden_dir):
     out = O.render_rays(full[idx].contiguous(), sc, sf, O.RenderConfig())
     _close(out["raw_fine"].numpy(), g["raw_fine_first64_hor0"], 5e-5)
     _close(out["z_fine"].numpy(), g["z_fine_first64_hor0"], 1e-6)
+    _close(out["weights_coarse"].numpy(), g["weights_coarse_hor0"][:64], 2e-6)
+    # the sampler ALONE on the reference's own coarse weights (all 4096 rays, both poses): bit-exact wherever torch.sum takes
+    # the order this build of torch took when the goldens were made; 1e-6 otherwise would already be
+    # a different cdf amplified, so exactness is what is asserted
+    t = torch.linspace(0., 1., 64)
+    z_c = (0.1 * (1. - t) + 10.0 * t).expand(4096, 64)
+    z_mid = .5 * (z_c[..., 1:] + z_c[..., :-1])
+    for pose in ("hor0", "hor30"):
+        zs = O.sample_pdf(z_mid, torch.from_numpy(g[f"weights_coarse_{pose}"])[..., 1:-1], 128)
+        assert torch.equal(zs, torch.from_numpy(g[f"z_samples_{pose}"])), pose
+    diag = O.sample_pdf_diagnostics(z_mid, torch.from_numpy(g["weights_coarse_hor0"])[..., 1:-1], 128)
+    assert np.median(diag["amp"].numpy()) > 1e3 and diag["amp"].max() < 2e4        # the typical ray is ill conditioned
+    assert (diag["min_denom"].numpy() >= 1e-5 * 0.999).all()                        # weights + 1e-5 keeps every step near or above the switch
     cliff = np.abs(g["sigma_last_fine_hor0"][:64]) < 1e-5
     _close(out["rgb_fine"].numpy()[~cliff], g["rgb_fine_hor0"][:64][~cliff], 5e-5)
 
