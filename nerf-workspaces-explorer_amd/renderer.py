@@ -322,6 +322,8 @@ class TiledRenderer:
         self._ctxs = (C.c_void_p * len(self.parts))(*[p._ctx for p in self.parts])
 
     def __getattr__(self, name):            # everything else: the first context (same device as the assembled frames)
+        if name in ("parts", "_lib", "_ctxs", "devices"):
+            raise AttributeError(name)      # not constructed yet: no delegation (and no recursion through self.parts)
         return getattr(self.parts[0], name)
 
     def close(self) -> None:
