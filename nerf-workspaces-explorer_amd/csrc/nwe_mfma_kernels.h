@@ -25,6 +25,10 @@
 //     statically in the gaps between them: the epilogue of tile t (bias, ReLU, hi/lo split) runs in
 //     stages between the MFMAs of tile t+1 (EpiPlan), LDS-DMA addressing is scalar and each piece has a
 //     gap of its own (DmaPlan), the A fragments are read three k-steps ahead.
+//   * template switches of render_mfma_kernel: X3 (three split products / single fp16 product), SPLIT (one packet per
+//     workgroup, samples dealt to the waves), FOLD (_feature_linear multiplied into the view layer by the packer, the product
+//     path), LEAN (only rgb / depth / acc of pinhole views: every other pointer compile-time null, no register spills).
+// This header holds the templates; nwe_mfma_inst_*.hip instantiate them (in parallel), nwe_kernel_mfma.hip dispatches.
 #pragma once
 #include "nwe_host.h"
 
