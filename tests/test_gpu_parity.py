@@ -1040,3 +1040,37 @@ def test_handler_renders_any_legal_shape(capsys):
         assert np.abs(got - ref["rgb_fine"].numpy())[ok].max() <= RGB_TOL, (D, Wn)
         text = capsys.readouterr().out
         assert ("no MFMA instantiation" in text) == (want == "f32")
+
+
+@pytest.mark.gpu
+def test_in_process_tiles_edge_cases():
+    """nwe_render_tiled at its edges: more tiles than rows (empty tiles), a context that was never given its networks (the
+    call fails on contexts[0] with the tile named, nothing is left writing), and flags from any tile reach the caller."""
+    sds = (nwe_amd.synthetic.thin_fog(_sd(1000, 4, 128)), _sd(1001, 4, 128))
+    one = nwe_amd.Renderer(0)
+    tiled = nwe_amd.TiledRenderer([0] * 5)
+    for r in (one, tiled):
+        r.set_network(0, sds[0]); r.set_network(1, sds[1]); r.set_sampling(16, 8)
+    fx, fy, cx, cy = O.intrinsics(3, 40)
+    pose = O.camera_pose((0.0, -0.5, -0.77, 0.0, -90.0, 0.0), (0, 0, 0, -30.0, 0.0, 0.0))[0].numpy()
+    kw = dict(fx=fx, fy=fy, cx=cx, cy=cy, near=0.1, far=10.0)
+    a, b = one.render(pose, 3, 40, **kw), tiled.render(pose, 3, 40, **kw)          # 3 rows over 5 tiles: two tiles are empty
+    for k in ("rgb", "depth", "acc"):
+        assert torch.equal(a[k], b[k]), k
+    # a NaN network output in the LAST tile's rows only must still set the caller's flag word
+    bad = {k: v.copy() for k, v in sds[1].items()}
+    bad["_rgb_linear.bias"][:] = np.nan
+    for r in (one, tiled):
+        r.set_network(1, bad)
+    a, b = one.render(pose, 3, 40, **kw), tiled.render(pose, 3, 40, **kw)
+    assert int(a["flags"].item()) & 1 and int(b["flags"].item()) == int(a["flags"].item())
+    # a context without networks
+    broken = nwe_amd.TiledRenderer([0, 0])
+    broken.parts[0].set_network(0, sds[0]); broken.parts[0].set_network(1, sds[1])
+    for p in broken.parts:
+        p.set_sampling(16, 8)
+    with pytest.raises(RuntimeError, match="tile 1: .*network not set"):
+        broken.render(pose, 3, 40, **kw)
+    torch.cuda.synchronize()
+    for r in (one, tiled, broken):
+        r.close()
