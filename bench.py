@@ -17,11 +17,18 @@ For N > 1 the line also carries, measured AFTER the timed region of the headline
 `in_process` = the same single frame through nwe_render_tiled from rank 0 alone (N contexts in one process,
             hipMemcpyPeerAsync into the frame): the path a GUI thread uses.  Best effort: an error is reported, not raised.
 
+At N = 1 the line also carries `configs`: the other BASELINE.json configurations the driver's one GPU can run, measured
+after the headline (kernel ms from the library's HIP events, best of three launches): C1 (64x64, 32 samples, 4x128, coarse
+only), C2 (400x400, 64 coarse samples, 8x256), the YAML's 320x240 GUI frame (64+128) and C5 on one GPU (32 poses x 800x800
+in ONE launch, frames/s).  They are parity-test cases (tests/test_gpu_parity.py), not bench lines; the numbers are there so
+that the driver's record holds them.
+
 `roofline` prices the render kernel (the only kernel of the path) against the dense fp16 MFMA peak with the
 ALGORITHMIC FLOPs of the reference formulation (2 x GEMM MACs, SURVEY.md §8d: 1 186 816 FLOP per MLP
 evaluation, 64 coarse + 192 fine evaluations per ray); its duration comes from HIP events recorded by the
 library on the launch stream around each launch.  `cpu_baseline` times the oracle (torch CPU, the reference's
-arithmetic) on a bounded sample of the same frame on this box's host cores.
+arithmetic) as BASELINE.md section 3 plans it: four reference chunks (32 768 rays) of the same frame, extrapolated linearly,
+and C1 in full, on every host core this process may use (count stated).
 """
 from __future__ import annotations
 
@@ -44,8 +51,9 @@ STRONG_STEPS = 5
 LIBRARY_GEMM_F16_TFLOPS = 1330.0   # measured on this pool, tools/gemm_reference.py
 POWER_CAPPED_F16_TFLOPS = 1650.0   # measured on this pool, see profiles/r01_ubench_mfma_power.txt
 PEAK_F16_TFLOPS = 2500.0   # dense fp16/bf16 MFMA peak, MI355X_MICROARCH.md
-TRAFFIC_PROFILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_pmc_traffic.json")
-CPU_SAMPLE_RAYS = 8192     # one reference chunk (inference.chunk = 1024*8): ~10 s of CPU work on 8-16 cores
+TRAFFIC_PROFILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r03_pmc_traffic.json")
+CPU_CHUNK = 8192           # inference.chunk = 1024*8 (nerf/configs/office_tokyo_config.yaml:41)
+CPU_SAMPLE_RAYS = 4 * CPU_CHUNK   # >= 4 chunks of C3, extrapolated linearly (cost per ray is constant)
 
 
 def sweep_pose(k: int, n: int) -> np.ndarray:
@@ -69,14 +77,14 @@ def kernel_source_sha() -> str:
 
 def profiled_traffic():
     """(bytes per C3 launch, note): HBM-side bytes from separate rocprofv3 --pmc passes over this same command
-    (tools/pmc_traffic.sh -> profiles/r02_pmc_traffic.json), used only when that profile was taken on the kernel sources
+    (tools/r03_profile.sh -> profiles/r03_pmc_traffic.json), used only when that profile was taken on the kernel sources
     in the tree; otherwise (None, why) - counters cannot be read inside this run."""
     try:
         prof = json.load(open(TRAFFIC_PROFILE))
     except (OSError, ValueError):
         return None, "no counter profile committed for this build"
     if prof.get("kernel_source_sha") != kernel_source_sha():
-        return None, f"profiles/r02_pmc_traffic.json was taken on kernel sources {prof.get('kernel_source_sha')}, not the ones in the tree"
+        return None, f"{os.path.basename(TRAFFIC_PROFILE)} was taken on kernel sources {prof.get('kernel_source_sha')}, not the ones in the tree"
     return float(prof["hbm_bytes_per_launch"]), prof.get("note", "")
 
 
@@ -90,25 +98,52 @@ def cpu_model() -> str:
     return "unknown"
 
 
-def cpu_baseline(sd_c, sd_f, pose):
-    """The oracle on one 8192-ray chunk taken from the middle of the frame, all host threads."""
-    from oracle import nerf_oracle as O
-    # the GPU box gives one GPU's job a 16-core share; more threads than that only oversubscribe the small GEMMs
+def host_threads() -> int:
+    """The host cores this process may actually use: its affinity mask, capped by the cgroup CPU quota (the GPU box shows
+    all 256 logical CPUs to a one-GPU job but schedules it on a 16-core quota: more threads than that only get throttled)."""
     try:
-        avail = len(os.sched_getaffinity(0))
+        n = len(os.sched_getaffinity(0))
     except AttributeError:
-        avail = os.cpu_count() or 1
-    torch.set_num_threads(min(16, avail))
+        n = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = max(1, min(n, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def progress(msg: str) -> None:
+    """A line on stderr per phase: the JSON line is the only thing on stdout, and a run that is silent for minutes looks hung."""
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
+def cpu_baseline(sd_c, sd_f, pose):
+    """the oracle on four 8192-ray reference chunks from the middle of the frame (the reference's
+    chunking: 8192 rays per chunk, 32768 points per MLP call), and the C1 frame in full; all host threads."""
+    from oracle import nerf_oracle as O
+    threads = host_threads()
+    torch.set_num_threads(threads)
     fx, fy, cx, cy = O.intrinsics(H, W)
     rays = O.create_rays(torch.from_numpy(pose)[None], H, W, fx, fy, cx, cy, 0.1, 10.0)[0]
     start = (H // 2) * W
     rays = rays[start:start + CPU_SAMPLE_RAYS].contiguous()
     t = lambda sd: {k: torch.from_numpy(v) for k, v in sd.items()}
-    cfg = O.RenderConfig(n_samples=NS, n_importance=NI)
+    cfg = O.RenderConfig(n_samples=NS, n_importance=NI, chunk=CPU_CHUNK)
+    progress(f"cpu baseline: {CPU_SAMPLE_RAYS} rays of the frame through the oracle on {threads} threads")
     t0 = time.perf_counter()
     ref = O.render_rays(rays, t(sd_c), t(sd_f), cfg, keep=("rgb_fine", "raw_fine", "z_fine"))
     dt = time.perf_counter() - t0
-    return rays, ref, dt, start, torch.get_num_threads()
+    # C1 in full: 64x64, 32 coarse samples, coarse-only 4x128 (BASELINE.json configs[0], the reference's own CPU-runnable case)
+    import nwe_amd
+    c1 = t(nwe_amd.synthetic.make_state_dict(1000, 4, 128))
+    f1 = O.intrinsics(64, 64)
+    t1 = time.perf_counter()
+    rays1 = O.create_rays(torch.from_numpy(pose)[None], 64, 64, *f1, 0.1, 10.0)[0]
+    O.render_rays(rays1, c1, None, O.RenderConfig(n_samples=32, n_importance=0, chunk=CPU_CHUNK), keep=("rgb_coarse",))
+    dt1 = time.perf_counter() - t1
+    return rays, ref, dt, start, threads, dt1
 
 
 def main() -> None:
@@ -118,6 +153,7 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--precision", default="f16x3", choices=["f16x3", "f16x1", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-configs", action="store_true", help="skip the `configs` object (C1, C2, GUI frame, C5 on one GPU)")
     ap.add_argument("--in-process-probe", type=int, default=0, metavar="N",
                     help="internal: render ONE frame through nwe_render_tiled on devices 0..N-1 from this process, print a JSON object, exit")
     ap.add_argument("--unfolded", action="store_true",
@@ -127,7 +163,7 @@ def main() -> None:
     import torch.distributed as dist
 
     import nwe_amd
-    from nwe_amd.dist import TileShardedRenderer
+    from nwe_amd.dist import TileShardedRenderer, gather_tiles
 
     if args.in_process_probe:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -180,6 +216,8 @@ def main() -> None:
             dist.barrier()
         torch.cuda.synchronize()
 
+    if rank == 0:
+        progress(f"{args.warmup} warm-up + {args.steps} timed steps of {frames_per_step} frame(s)")
     for _ in range(args.warmup):
         step()
     kernel_ms.clear()
@@ -202,25 +240,55 @@ def main() -> None:
 
     # ---- after the headline measurement: the single-frame (strong scaling) case, N > 1 only ---------------------------------
     strong = None
+    rccl = None
     if world > 1:
         one = poses[:1]
-        skm = []
+        skm, gms = [], []
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         for _ in range(2):
             tsr.render_frames(one, H, W)
         fence()
         t1 = time.perf_counter()
         for _ in range(STRONG_STEPS):
-            tsr.render_frames(one, H, W)
+            tile = tsr.render_local(one, H, W)
             skm.append(h.renderer.last_kernel_ms())
+            ev0.record()                                  # torch's current stream: the one the gather is queued on
+            gather_tiles(tile, H, rank, world)
+            ev1.record()
+            ev1.synchronize()
+            gms.append(ev0.elapsed_time(ev1))
         fence()
-        st = torch.tensor([time.perf_counter() - t1, float(np.mean(skm))], dtype=torch.float64, device=red_dev)
+        st = torch.tensor([time.perf_counter() - t1, float(np.mean(skm)), float(np.mean(gms))], dtype=torch.float64, device=red_dev)
         dist.all_reduce(st, op=dist.ReduceOp.MAX)
         ms_frame = float(st[0].item()) / STRONG_STEPS * 1e3
+        # like for like: ONE 800x800 frame on this rank alone, wall clock, in this same run
+        fence()
+        single_ms = None
+        if rank == 0:
+            for _ in range(2):
+                h.render_batch(one, H, W)
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            for _ in range(3):
+                h.render_batch(one, H, W)
+            torch.cuda.synchronize()
+            single_ms = (time.perf_counter() - t2) / 3 * 1e3
+        fence()
         strong = {"workload": f"C4: ONE 800x800 frame as {world} row tiles ({H // world * W} rays per rank) + RCCL gather",
                   "ms_per_frame": ms_frame, "frames_per_s": 1e3 / ms_frame, "ray_samples_per_s": H * W * (NS + NI) / ms_frame * 1e3,
-                  "kernel_ms_slowest_rank": float(st[1].item()), "steps": STRONG_STEPS,
-                  "speedup_vs_this_run_single_gpu_frame": k_ms / ms_frame, "note": "single_gpu_frame = this run's kernel time for "
-                  "640 000 rays on one rank (the weak-scaling launch); ideal speedup = n_gpus"}
+                  "kernel_ms_slowest_rank": float(st[1].item()), "gather_ms_slowest_rank": float(st[2].item()), "steps": STRONG_STEPS,
+                  "single_gpu_frame_ms_this_run": single_ms,
+                  "speedup_vs_single_gpu_frame": None if single_ms is None else single_ms / ms_frame,
+                  "note": "wall clock on both sides: one frame on rank 0 alone vs the same frame sharded over all ranks incl. the gather "
+                          "(gather_ms = events around dist.gather + reassembly on the stream it runs on); ideal speedup = n_gpus"}
+        # what the job actually ran on: every rank reports its device
+        prop = torch.cuda.get_device_properties(local_rank)
+        mine = {"rank": rank, "local_rank": local_rank, "device": prop.name, "pci_bus_id": getattr(prop, "pci_bus_id", None),
+                "uuid": str(getattr(prop, "uuid", "")), "cus": prop.multi_processor_count}
+        everyone = [None] * world
+        dist.all_gather_object(everyone, mine, group=host_group)
+        rccl = {"world": dist.get_world_size(), "backend": dist.get_backend(), "devices": everyone,
+                "distinct_devices": len({(d["pci_bus_id"], d["uuid"], d["local_rank"]) for d in everyone})}
 
     if rank == 0:
         r0 = h.renderer
@@ -263,15 +331,21 @@ def main() -> None:
         }
         if strong is not None:
             line["strong"] = strong
+            line["rccl"] = rccl
             line["in_process"] = in_process_probe(args, world)
+        if world == 1 and not args.no_configs:
+            line["configs"] = other_configs(args)
         if world == 1 and not args.no_cpu_baseline:
-            rays, ref, dt, start, threads = cpu_baseline(sd_c, sd_f, poses[0])
+            rays, ref, dt, start, threads, dt_c1 = cpu_baseline(sd_c, sd_f, poses[0])
             cpu_value = CPU_SAMPLE_RAYS * (NS + NI) / dt
             line["cpu_baseline"] = {"value": cpu_value, "unit": "ray-samples/s", "cores": threads, "kind": "port",
                                     "cpu_model": cpu_model(), "logical_cpus_visible": os.cpu_count(),
-                                    "sample": f"{CPU_SAMPLE_RAYS} rays (rows {start // W}..) of the same frame = one reference chunk, "
-                                              f"oracle/nerf_oracle.py on torch CPU fp32, {threads} threads, {dt:.1f} s",
-                                    "frame_s_extrapolated": H * W * (NS + NI) / cpu_value}
+                                    "sample": f"{CPU_SAMPLE_RAYS} rays (rows {start // W}..) of the same frame = {CPU_SAMPLE_RAYS // CPU_CHUNK} reference "
+                                              f"chunks of {CPU_CHUNK} rays, oracle/nerf_oracle.py on torch CPU fp32, {threads} threads (= the cores this "
+                                              f"process may use: affinity mask capped by the cgroup CPU quota), {dt:.1f} s; C1 (64x64, 32 samples, 4x128) in full: {dt_c1:.2f} s",
+                                    "mlp_evals_per_s": CPU_SAMPLE_RAYS * evals_per_ray / dt, "rays_per_s": CPU_SAMPLE_RAYS / dt,
+                                    "frame_s_extrapolated": H * W * (NS + NI) / cpu_value,
+                                    "c1_frame_s": dt_c1, "c1_mlp_evals_per_s": 64 * 64 * 32 / dt_c1}
             # image quality of the timed frame against the oracle on the same rays (metric: "PSNR vs ref")
             got = frame["rgb"][0].reshape(-1, 3)[start:start + CPU_SAMPLE_RAYS].cpu().numpy()
             mse = float(np.mean((got.astype(np.float64) - ref["rgb_fine"].numpy().astype(np.float64)) ** 2))
@@ -293,6 +367,21 @@ def main() -> None:
                 "note": "random unrelated coarse/fine nets: the reference's inverse-CDF sampling amplifies the ~5e-7 difference "
                         "between two fp32 evaluations of the coarse MLP by up to 1e4 in depth (DESIGN.md section 6); every ray "
                         "above 1e-4 is one whose sample depths moved, every ray sampled where the oracle sampled it is within 1e-4"}
+            # the parity gate of the timed frame: a regression FAILS the run (no line) instead of printing a number beside it.
+            # Bounds as in tests/test_gpu_parity.py::test_c3_subset_against_golden (measured 0.5-0.8 % / 6.5e-4 / 94-97 dB).
+            q = line["rgb_abs_err_vs_oracle"]
+            problems = []
+            if q["above_1e-4_on_those"] != 0:
+                problems.append(f"{q['above_1e-4_on_those']} rays sampled where the oracle sampled them are above 1e-4 (max {q['max_err_on_those']:.2e})")
+            if q["share_above_1e-4"] >= 0.012:
+                problems.append(f"{q['share_above_1e-4']:.2%} of the rays above 1e-4 (bound 1.2 %)")
+            if float(err[~cliff].max()) >= 1.5e-3:
+                problems.append(f"max abs error {float(err[~cliff].max()):.2e} (bound 1.5e-3)")
+            if line["psnr_vs_oracle_db"] <= 50.0:
+                problems.append(f"PSNR {line['psnr_vs_oracle_db']:.1f} dB (bound 50)")
+            if problems:
+                print(json.dumps(line), file=sys.stderr, flush=True)
+                raise SystemExit("bench.py: the timed frame does not match the oracle: " + "; ".join(problems))
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier(group=host_group)      # ranks != 0 wait here, on the host, while rank 0's child renders on all devices
@@ -317,7 +406,8 @@ def in_process_probe(args, n):
 
 def in_process_frame(args, sd_c, sd_f, pose, n, n_visible):
     """One C3 frame through nwe_render_tiled from this process alone: n contexts on devices 0..n-1, tiles copied into the
-    frame with hipMemcpyPeerAsync.  The other ranks are idle (behind the barrier) while this runs."""
+    frame with hipMemcpyPeerAsync.  The other ranks are idle (behind the barrier) while this runs.  A frame that did not
+    go through nwe_render_tiled, or a tile that did not render, is an error, not a number."""
     try:
         import nwe_amd
         devices = list(range(n))
@@ -336,10 +426,73 @@ def in_process_frame(args, sd_c, sd_f, pose, n, n_visible):
             out = hh.render_batch(pose[None], H, W)
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) / STRONG_STEPS * 1e3
-        return {"workload": f"ONE 800x800 frame as {n} row tiles on devices {devices} from one process (nwe_render_tiled)",
-                "ms_per_frame": ms, "tile_kernel_ms": hh.renderer.tile_kernel_ms(), "flags": int(out["flags"].item())}
+        r = hh.renderer
+        tile_ms = r.tile_kernel_ms()
+        res = {"workload": f"ONE 800x800 frame as {n} row tiles on devices {devices} from one process (nwe_render_tiled)",
+               "ms_per_frame": ms, "tile_kernel_ms": tile_ms, "tiles": len(tile_ms), "peer_access": r.peer_access(),
+               "warning": r.last_warning(), "flags": int(out["flags"].item()),
+               "current_device_after": torch.cuda.current_device()}
+        if not r.last_tiled:
+            res["error"] = "the frame did not go through nwe_render_tiled (single-context path taken)"
+        elif len(tile_ms) != n or any(not (t > 0) for t in tile_ms):
+            res["error"] = f"not every tile rendered: kernel ms per tile {tile_ms}"
+        else:
+            # the frame must be the single-context frame, bit for bit
+            one = nwe_amd.NeRFReplicaInferenceHandler("office_tokyo", "synthetic", precision=args.precision, device=devices[0])
+            one.set_sampling(NS, NI)
+            one.initialize_models(state_dicts=(sd_c, sd_f))
+            ref = one.render_batch(pose[None], H, W)
+            res["equal_to_single_context_frame"] = bool(torch.equal(ref["rgb"], out["rgb"]) and torch.equal(ref["depth"], out["depth"]))
+            if not res["equal_to_single_context_frame"]:
+                res["error"] = "tiled frame differs from the single-context frame"
+        return res
     except Exception as exc:   # noqa: BLE001 - a diagnostic leg must not take the headline number down with it
         return {"error": f"{type(exc).__name__}: {exc}"}
+
+
+def other_configs(args):
+    """The BASELINE.json configurations besides the headline that one GPU can run: kernel time from
+    the library's HIP events, best of three launches after one warm-up; C5 = 32 poses x 800x800 in ONE launch (wall clock too).
+    The poses are the bench's GUI sweep; weights from the same generator (4x128 for C1)."""
+    import nwe_amd
+    res = {}
+    cases = [("C1", "64x64, 32 coarse samples, coarse-only 4x128", 64, 64, 32, 0, 4, 128, 1),
+             ("C2", "400x400, 64 coarse samples, 8x256", 400, 400, 64, 0, 8, 256, 1),
+             ("GUI", "320x240 (the YAML's image size), 64+128, 8x256", 240, 320, 64, 128, 8, 256, 1),
+             ("C5_one_gpu", "32 poses x 800x800, 64+128, 8x256 in ONE launch on one GPU", 800, 800, 64, 128, 8, 256, 32)]
+    for key, what, hh, ww, ns, ni, D, Wn, n_poses in cases:
+        progress(f"config {key}: {what}")
+        try:
+            hd = nwe_amd.NeRFReplicaInferenceHandler("office_tokyo", "synthetic", precision=args.precision)
+            hd.set_sampling(ns, ni)
+            hd.initialize_models(state_dicts=(nwe_amd.synthetic.make_state_dict(1000, D, Wn),
+                                              nwe_amd.synthetic.make_state_dict(1001, D, Wn) if ni else None))
+            ps = np.stack([sweep_pose(k, n_poses) for k in range(n_poses)])
+            reps = 1 if n_poses > 1 else 3
+            if n_poses == 1:
+                hd.render_batch(ps, hh, ww)
+            ms, wall = [], []
+            for _ in range(reps):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                out = hd.render_batch(ps, hh, ww)
+                torch.cuda.synchronize()
+                wall.append((time.perf_counter() - t0) * 1e3)
+                ms.append(hd.renderer.last_kernel_ms())
+            k = min(ms)
+            rays = n_poses * hh * ww
+            evals = rays * (ns + (ns + ni if ni else 0))
+            flops = rays * (ns * hd.renderer.flops_per_eval(0) + ((ns + ni) * hd.renderer.flops_per_eval(1) if ni else 0))
+            res[key] = {"workload": what, "kernel_ms": k, "wall_ms": min(wall), "rays": rays,
+                        "ray_samples_per_s": rays * (ns + ni) / k * 1e3, "mlp_evals_per_s": evals / k * 1e3,
+                        "algorithmic_tflops": flops / k / 1e9, "frac_of_dense_f16_peak": flops / k / 1e9 / PEAK_F16_TFLOPS,
+                        "plan": hd.renderer.debug_last_plan(), "flags": int(out["flags"].item())}
+            if n_poses > 1:
+                res[key]["frames_per_s"] = n_poses / min(wall) * 1e3
+            del hd, out
+        except Exception as exc:   # noqa: BLE001 - reported, the headline stands
+            res[key] = {"workload": what, "error": f"{type(exc).__name__}: {exc}"}
+    return res
 
 
 if __name__ == "__main__":

@@ -134,6 +134,13 @@ int nwe_render_tiled(nwe_ctx *const *contexts, int n_ctx, const float *c2w, int 
                      float cx, float cy, float near, float far, int precision, float *rgb_dev, float *depth_dev,
                      float *acc_dev, uint32_t *flags_dev, void *stream);
 
+/* What the last nwe_render_tiled on contexts[0] went through without failing but the caller should know (peer access
+ * between two devices not available or not enabled: the tile copies are then staged by the runtime); "" if nothing. */
+const char *nwe_last_warning(const nwe_ctx *ctx);
+/* How `tile`'s device reaches `first`'s (contexts[0]'s) memory in nwe_render_tiled: 1 direct (same device, or peer access
+ * over xGMI enabled), 0 hipDeviceCanAccessPeer says no (staged copies), -1 the query or hipDeviceEnablePeerAccess failed. */
+int nwe_debug_peer_access(const nwe_ctx *first, const nwe_ctx *tile);
+
 /* Generate the rays of nwe_render() without rendering them: DEVICE rays_out [n_poses*(row_end-row_begin)*W, 11]
  * fp32 = [o(3) d(3) near far viewdir(3)], bit-identical to the reference's CPU result.
  * Replaces: create_rays (nerf/rays/rays.py:6-32). */
@@ -152,8 +159,10 @@ int nwe_to8b(nwe_ctx *ctx, const float *rgb_dev, uint8_t *out_dev, int64_t n, vo
 /* Algorithmic FLOPs (2 x GEMM MACs of the reference formulation) of one MLP evaluation of network `which`. */
 int64_t nwe_flops_per_eval(const nwe_ctx *ctx, int which);
 
-/* Time of the most recent render launch on this context, from HIP events recorded on its stream
- * around the kernel; blocks until that launch has finished.  Returns < 0 if nothing was launched. */
+/* Time of the most recent RENDER launch on this context (nwe_render / nwe_render_rays / this context's tile of
+ * nwe_render_tiled; nwe_create_rays does not count), from HIP events recorded on its stream around the kernel; blocks
+ * until that launch has finished.  Returns < 0 if nothing was launched.  Like every entry point it leaves the calling
+ * thread's current HIP device as it found it. */
 float nwe_last_kernel_ms(nwe_ctx *ctx);
 
 /* --- test hooks ------------------------------------------------------------------------------- */

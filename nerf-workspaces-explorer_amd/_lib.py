@@ -20,7 +20,8 @@ OUTPUT_FIELDS = ("rgb", "depth", "acc", "disp", "z_std", "rgb_coarse", "depth_co
 SYMBOLS = ("nwe_create", "nwe_destroy", "nwe_last_error", "nwe_set_network", "nwe_set_sampling", "nwe_render", "nwe_render_tiled",
            "nwe_create_rays", "nwe_render_rays", "nwe_to8b", "nwe_flops_per_eval", "nwe_last_kernel_ms", "nwe_packed_bytes",
            "nwe_packed_copy", "nwe_packed_bias_count", "nwe_packed_bias_copy", "nwe_packed_scale",
-           "nwe_debug_set_fine_depths", "nwe_debug_set_raw", "nwe_debug_set_coarse_weights", "nwe_debug_set_fold", "nwe_set_train_tables", "nwe_set_white_background", "nwe_debug_set_decomposition", "nwe_debug_last_plan", "nwe_debug_set_stamps", "nwe_selftest")
+           "nwe_debug_set_fine_depths", "nwe_debug_set_raw", "nwe_debug_set_coarse_weights", "nwe_debug_set_fold", "nwe_set_train_tables", "nwe_set_white_background", "nwe_debug_set_decomposition", "nwe_debug_last_plan", "nwe_debug_set_stamps", "nwe_selftest",
+           "nwe_last_warning", "nwe_debug_peer_access")
 
 
 class Outputs(C.Structure):
@@ -74,6 +75,8 @@ def load() -> C.CDLL:
         "nwe_debug_last_plan": (I, [P]),
         "nwe_debug_set_stamps": (I, [P, P]),
         "nwe_selftest": (I, [P, C.POINTER(C.c_int32)]),
+        "nwe_last_warning": (C.c_char_p, [P]),
+        "nwe_debug_peer_access": (I, [P, P]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)   # AttributeError if the symbol is missing: loud by design

@@ -50,7 +50,7 @@ struct nwe_ctx {
     };
     static constexpr int kSlots = 4;
     Slot slots[kSlots];
-    int next_slot = 0, last_slot = -1;
+    int next_slot = 0, last_slot = -1;   // last_slot: the most recent RENDER launch (nwe_last_kernel_ms), not nwe_create_rays
     const float* dbg_z_fine = nullptr;
     const float *dbg_raw_c = nullptr, *dbg_raw_f = nullptr, *dbg_w = nullptr;   // nwe_debug_set_raw / _coarse_weights, one call
     int fold = 1;             // nwe_debug_set_fold: read by nwe_set_network
@@ -64,6 +64,8 @@ struct nwe_ctx {
     hipEvent_t frame_ready = nullptr;   // contexts[0] only: recorded on the caller's stream when the call starts
     uint32_t* flag_parts = nullptr;     // contexts[0] only: one flag word per tile, on its device
     int flag_parts_cap = 0;
+    int peer_access = -2;               // this context's device -> contexts[0]'s device: 1 direct, 0 staged, -1 query/enable failed, -2 not asked yet
+    std::string warn;                   // nwe_last_warning: what did not fail the call but the caller should know
     int white_bkgd = 0;
     int decomposition = -1;   // nwe_debug_set_decomposition
     int last_plan = -1;       // nwe_debug_last_plan
@@ -78,6 +80,16 @@ int fail(nwe_ctx* c, int code, const std::string& msg) {
     if (c) c->err = msg; else g_create_error = msg;
     return code;
 }
+
+// Every entry point that switches the calling thread's HIP device puts it back on return: a GUI or bench thread that
+// queries a tile of another device must not find its later torch calls on that device.
+struct DeviceGuard {
+    int prev = -1;
+    DeviceGuard() { if (hipGetDevice(&prev) != hipSuccess) { prev = -1; (void)hipGetLastError(); } }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+    DeviceGuard(const DeviceGuard&) = delete;
+    DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
 
 #define HIPCHK(ctx, expr)                                                                          \
     do {                                                                                           \
@@ -271,14 +283,14 @@ __global__ void create_rays_kernel(RenderArgs a, float* __restrict__ out) {
 }
 
 // The slot of the next launch: waits for the launch that used it kSlots launches ago (normally long finished).
-int acquire_slot(nwe_ctx* c, nwe_ctx::Slot** out) {
+int acquire_slot(nwe_ctx* c, nwe_ctx::Slot** out, bool render = true) {
     nwe_ctx::Slot& s = c->slots[c->next_slot];
     if (!s.ev0) {
         HIPCHK(c, hipEventCreate(&s.ev0));
         HIPCHK(c, hipEventCreate(&s.ev1));
     }
     if (s.used) HIPCHK(c, hipEventSynchronize(s.ev1));
-    c->last_slot = c->next_slot;
+    if (render) c->last_slot = c->next_slot;
     c->next_slot = (c->next_slot + 1) % nwe_ctx::kSlots;
     *out = &s;
     return NWE_OK;
@@ -363,6 +375,7 @@ int nwe_create(nwe_ctx** out, int device) {
 void nwe_destroy(nwe_ctx* c) {
     if (!c) return;
     if (!c->host_only) {
+        DeviceGuard guard;
         (void)hipSetDevice(c->device);
         for (NetState& n : c->net) { if (n.d_blob) (void)hipFree(n.d_blob); if (n.d_stream) (void)hipFree(n.d_stream); if (n.d_bias) (void)hipFree(n.d_bias); }
         if (c->d_t) (void)hipFree(c->d_t);
@@ -410,6 +423,7 @@ int nwe_set_network(nwe_ctx* c, int which, int depth, int width, int in_xyz, int
     n.mf.n_chunks = (int)(n.bias_tab.size() / 32);
     n.mf.inv_scale = 1.f / n.w_scale;
     if (!c->host_only) {
+        DeviceGuard guard;
         HIPCHK(c, hipSetDevice(c->device));
         if (n.d_blob) { (void)hipFree(n.d_blob); n.d_blob = nullptr; }
         if (n.d_stream) { (void)hipFree(n.d_stream); n.d_stream = nullptr; }
@@ -438,6 +452,7 @@ int nwe_set_sampling(nwe_ctx* c, const float* t_vals, const float* one_minus_t, 
     if (n_importance > 0 && (!u || n_samples < 3)) return fail(c, NWE_ERR_INVALID, "importance sampling needs u and n_samples >= 3");
     c->ns = n_samples; c->ni = n_importance;
     if (c->host_only) return NWE_OK;
+    DeviceGuard guard;
     HIPCHK(c, hipSetDevice(c->device));
     if (!c->d_t) {
         HIPCHK(c, hipMalloc(&c->d_t, (2 * kMaxSamples + kMaxImportance) * sizeof(float)));
@@ -457,6 +472,7 @@ int nwe_render(nwe_ctx* c, const float* c2w, int n_poses, int H, int W, float fx
     if (!c2w || n_poses < 1 || H < 1 || W < 1 || row_begin < 0 || row_end > H || row_begin > row_end)
         return fail(c, NWE_ERR_INVALID, "bad pose / image / row range");
     if (!(fx != 0.f) || !(fy != 0.f)) return fail(c, NWE_ERR_INVALID, "fx and fy must be non-zero");
+    DeviceGuard guard;
     HIPCHK(c, hipSetDevice(c->device));
     nwe_ctx::Slot* slot = nullptr;
     rc = acquire_slot(c, &slot);
@@ -482,6 +498,8 @@ int nwe_render_tiled(nwe_ctx* const* ctxs, int n_ctx, const float* c2w, int n_po
         if (!ctxs[i] || ctxs[i]->host_only) return fail(c0, NWE_ERR_INVALID, "nwe_render_tiled: null or host-only context");
     if (!c2w || n_poses < 1 || H < 1 || W < 1) return fail(c0, NWE_ERR_INVALID, "bad pose / image");
     hipStream_t stream0 = (hipStream_t)stream_;
+    DeviceGuard guard;
+    c0->warn.clear();
     // the caller's buffers may still be in use by earlier work on its stream: every tile stream starts behind this point
     HIPCHK(c0, hipSetDevice(c0->device));
     if (!c0->frame_ready) HIPCHK(c0, hipEventCreateWithFlags(&c0->frame_ready, hipEventDisableTiming));
@@ -504,13 +522,37 @@ int nwe_render_tiled(nwe_ctx* const* ctxs, int n_ctx, const float* c2w, int n_po
                 HIPCHK(c, hipStreamCreateWithFlags(&c->tile_stream, hipStreamNonBlocking));
                 HIPCHK(c, hipEventCreateWithFlags(&c->tile_done, hipEventDisableTiming));
                 HIPCHK(c, hipMalloc(&c->tile_flags, sizeof(uint32_t)));
+            }
+            if (c->peer_access == -2) {
+                // direct xGMI copies into the frame; without peer access the runtime stages the copy through the host.  Neither
+                // outcome fails the call, but the caller can read it (nwe_debug_peer_access, nwe_last_warning).
+                c->peer_access = 1;
                 if (c->device != c0->device) {
                     int can = 0;
-                    (void)hipDeviceCanAccessPeer(&can, c->device, c0->device);
-                    // direct xGMI copies into the frame; without peer access the runtime stages the copy through the host
-                    if (can && hipDeviceEnablePeerAccess(c0->device, 0) != hipSuccess) (void)hipGetLastError();   // "already enabled" included
+                    hipError_t e = hipDeviceCanAccessPeer(&can, c->device, c0->device);
+                    if (e == hipSuccess && can) {
+                        e = hipDeviceEnablePeerAccess(c0->device, 0);
+                        if (e == hipErrorPeerAccessAlreadyEnabled) { (void)hipGetLastError(); e = hipSuccess; }
+                    }
+                    if (e != hipSuccess) {
+                        (void)hipGetLastError();
+                        c->peer_access = -1;
+                        c0->warn += "tile " + std::to_string(i) + ": peer access device " + std::to_string(c->device) + " -> " + std::to_string(c0->device) +
+                                    " not enabled (" + hipGetErrorString(e) + "), copies are staged; ";
+                    } else if (!can) {
+                        c->peer_access = 0;
+                        c0->warn += "tile " + std::to_string(i) + ": device " + std::to_string(c->device) + " cannot access device " + std::to_string(c0->device) +
+                                    " directly, copies are staged; ";
+                    }
                 }
             }
+            // Whatever happens below, stream0 must wait for everything this call has queued on the tile stream: the event is
+            // recorded on EVERY exit of this step once the stream exists (a failing copy after earlier copies were queued
+            // would otherwise leave stream0 waiting on the previous frame's already-completed event).
+            struct RecordOnExit {
+                nwe_ctx* c;
+                ~RecordOnExit() { if (c->tile_done && c->tile_stream && hipEventRecord(c->tile_done, c->tile_stream) != hipSuccess) (void)hipGetLastError(); }
+            } record_on_exit{c};
             const size_t need = (size_t)n_poses * px * 5;
             if (c->tile_cap < need) {
                 HIPCHK(c, hipStreamSynchronize(c->tile_stream));
@@ -542,14 +584,14 @@ int nwe_render_tiled(nwe_ctx* const* ctxs, int n_ctx, const float* c2w, int n_po
                 }
                 HIPCHK(c, hipMemcpyPeerAsync(c0->flag_parts + i, c0->device, c->tile_flags, c->device, sizeof(uint32_t), c->tile_stream));
             }
-            HIPCHK(c, hipEventRecord(c->tile_done, c->tile_stream));
-            return NWE_OK;
+            return NWE_OK;   // record_on_exit records tile_done
         };
         rc_all = step();
         if (rc_all != NWE_OK && c != c0) c0->err = "tile " + std::to_string(i) + ": " + c->err;
         r0 = r1;
     }
-    // the caller's stream continues when every tile has landed (also on the error path: nothing may still be writing)
+    // the caller's stream continues when every tile has landed (also on the error path: nothing may still be writing;
+    // every tile that queued anything has re-recorded its event, see record_on_exit)
     (void)hipSetDevice(c0->device);
     for (int i = 0; i < n_ctx; ++i)
         if (ctxs[i]->tile_done) (void)hipStreamWaitEvent(stream0, ctxs[i]->tile_done, 0);
@@ -566,9 +608,10 @@ int nwe_create_rays(nwe_ctx* c, const float* c2w, int n_poses, int H, int W, flo
     if (!c || c->host_only) return fail(c, NWE_ERR_STATE, "needs a device context");
     if (!c2w || !rays_out_dev || n_poses < 1 || H < 1 || W < 1 || row_begin < 0 || row_end > H || row_begin > row_end)
         return fail(c, NWE_ERR_INVALID, "bad pose / image / row range");
+    DeviceGuard guard;
     HIPCHK(c, hipSetDevice(c->device));
     nwe_ctx::Slot* slot = nullptr;
-    int rc = acquire_slot(c, &slot);
+    int rc = acquire_slot(c, &slot, false);
     if (rc) return rc;
     rc = upload_poses(c, *slot, c2w, n_poses, (hipStream_t)stream);
     if (rc) return rc;
@@ -595,6 +638,7 @@ int nwe_render_rays(nwe_ctx* c, const float* rays_dev, int64_t n_rays, int preci
         c->trn_t = c->trn_nc = c->trn_nf = c->trn_u = nullptr;
         return NWE_OK;
     }
+    DeviceGuard guard;
     HIPCHK(c, hipSetDevice(c->device));
     nwe_ctx::Slot* slot = nullptr;
     rc = acquire_slot(c, &slot);
@@ -612,6 +656,7 @@ int nwe_render_rays(nwe_ctx* c, const float* rays_dev, int64_t n_rays, int preci
 int nwe_to8b(nwe_ctx* c, const float* rgb_dev, uint8_t* out_dev, int64_t n, void* stream) {
     if (!c || c->host_only || !rgb_dev || !out_dev || n < 0) return fail(c, NWE_ERR_INVALID, "bad argument");
     if (n == 0) return NWE_OK;
+    DeviceGuard guard;
     HIPCHK(c, hipSetDevice(c->device));
     hipLaunchKernelGGL(to8b_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, rgb_dev, out_dev, n);
     HIPCHK(c, hipGetLastError());
@@ -626,6 +671,7 @@ int64_t nwe_flops_per_eval(const nwe_ctx* c, int which) {
 float nwe_last_kernel_ms(nwe_ctx* c) {
     if (!c || c->host_only || c->last_slot < 0 || !c->slots[c->last_slot].used) return -1.f;
     const nwe_ctx::Slot& s = c->slots[c->last_slot];
+    DeviceGuard guard;
     hipError_t e = hipSetDevice(c->device);
     if (e == hipSuccess) e = hipEventSynchronize(s.ev1);
     float ms = -1.f;
@@ -695,6 +741,17 @@ int nwe_debug_set_decomposition(nwe_ctx* c, int mode) {
 
 int nwe_debug_last_plan(const nwe_ctx* c) { return c ? c->last_plan : -1; }
 
+int nwe_debug_peer_access(const nwe_ctx* first, const nwe_ctx* tile) {
+    if (!first || !tile || first->host_only || tile->host_only) return -1;
+    if (tile->peer_access != -2) return tile->peer_access;
+    if (tile->device == first->device) return 1;
+    int can = 0;
+    if (hipDeviceCanAccessPeer(&can, tile->device, first->device) != hipSuccess) { (void)hipGetLastError(); return -1; }
+    return can ? 1 : 0;
+}
+
+const char* nwe_last_warning(const nwe_ctx* c) { return c ? c->warn.c_str() : ""; }
+
 int nwe_debug_set_stamps(nwe_ctx* c, unsigned long long* per_wave_dev) {
     if (!c) return NWE_ERR_INVALID;
     c->stamps = per_wave_dev;
@@ -716,6 +773,7 @@ int nwe_set_train_tables(nwe_ctx* c, const float* t_rand_dev, const float* noise
 
 int nwe_selftest(nwe_ctx* c, int32_t* report8) {
     if (!c || c->host_only || !report8) return fail(c, NWE_ERR_INVALID, "bad argument");
+    DeviceGuard guard;
     HIPCHK(c, hipSetDevice(c->device));
     const int rc = run_selftest(report8, nullptr);
     if (rc == -1) return fail(c, NWE_ERR_HIP, "selftest: HIP failure");

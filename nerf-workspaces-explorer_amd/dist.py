@@ -54,11 +54,16 @@ def gather_tiles(tile: torch.Tensor, H: int, rank: int, world: int, dst: int = 0
     device = tile.device
     if dist.get_backend(group) == "gloo" and send.is_cuda:
         send = send.cpu()        # gloo gathers host tensors (CPU tests, several ranks sharing one GPU); nccl = RCCL stays on device
-    bufs = [torch.empty_like(send) for _ in range(world)] if rank == dst else None
-    dist.gather(send, bufs, dst=dst, group=group)
     if rank != dst:
+        dist.gather(send, None, dst=dst, group=group)
         return None
-    return torch.cat([bufs[r][:, : ranges[r][1] - ranges[r][0]] for r in range(world)], dim=1).to(device)
+    bufs = [torch.empty_like(send) for _ in range(world)]
+    dist.gather(send, bufs, dst=dst, group=group)
+    # reassemble into ONE preallocated frame on the tile's device: no cat() of world slabs followed by a second copy
+    full = torch.empty((B, H, W, C), dtype=tile.dtype, device=device)
+    for r, (a, b) in enumerate(ranges):
+        full[:, a:b].copy_(bufs[r][:, : b - a], non_blocking=True)
+    return full
 
 
 class TileShardedRenderer:

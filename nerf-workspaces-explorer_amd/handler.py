@@ -163,8 +163,9 @@ class NeRFReplicaInferenceHandler:
         fx, fy, cx, cy = pinhole_intrinsics(H, W)
         poses = np.asarray(poses, dtype=np.float32).reshape(-1, 4, 4)
         r0, r1 = rows if rows is not None else (0, H)
+        # rows=None stays None: "the whole frame" is what a TiledRenderer splits over its devices
         res = r.render(poses, H, W, fx=fx, fy=fy, cx=cx, cy=cy, near=self._depth_close_bound, far=self._depth_far_bound,
-                       rows=(r0, r1), precision=precision or self._precision, outputs=outputs)
+                       rows=None if rows is None else (r0, r1), precision=precision or self._precision, outputs=outputs)
         out = {}
         for k, v in res.items():
             if k == "flags":

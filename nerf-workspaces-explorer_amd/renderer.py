@@ -320,9 +320,10 @@ class TiledRenderer:
         self.devices = [int(d) for d in devices]
         self._lib = self.parts[0]._lib
         self._ctxs = (C.c_void_p * len(self.parts))(*[p._ctx for p in self.parts])
+        self.last_tiled = False                 # did the last render() go through nwe_render_tiled?
 
     def __getattr__(self, name):            # everything else: the first context (same device as the assembled frames)
-        if name in ("parts", "_lib", "_ctxs", "devices"):
+        if name in ("parts", "_lib", "_ctxs", "devices", "last_tiled"):
             raise AttributeError(name)      # not constructed yet: no delegation (and no recursion through self.parts)
         return getattr(self.parts[0], name)
 
@@ -348,9 +349,12 @@ class TiledRenderer:
     def render(self, c2w, H: int, W: int, *, fx: float, fy: float, cx: float, cy: float, near: float, far: float,
                rows: Optional[Tuple[int, int]] = None, precision: str = "f16x3",
                outputs: Sequence[str] = ("rgb", "depth", "acc")) -> Dict[str, torch.Tensor]:
-        """Whole frames [B*H*W, ...] on the first device.  A caller that asks for a row range, or for outputs other than
-        rgb / depth / acc, gets the single-context path (those are test and diagnostic surfaces)."""
-        if rows is not None or not set(outputs) <= {"rgb", "depth", "acc"}:
+        """Whole frames [B*H*W, ...] on the first device.  A caller that asks for a proper row range, or for outputs other
+        than rgb / depth / acc, gets the single-context path (those are test and diagnostic surfaces); ``rows=(0, H)`` is the
+        whole frame and is tiled like ``rows=None``."""
+        whole = rows is None or (int(rows[0]), int(rows[1])) == (0, H)
+        self.last_tiled = whole and set(outputs) <= {"rgb", "depth", "acc"}
+        if not self.last_tiled:
             return self.parts[0].render(c2w, H, W, fx=fx, fy=fy, cx=cx, cy=cy, near=near, far=far, rows=rows, precision=precision,
                                         outputs=outputs)
         poses = np.ascontiguousarray(np.asarray(c2w, dtype=np.float32).reshape(-1, 4, 4))
@@ -367,5 +371,15 @@ class TiledRenderer:
         return res
 
     def tile_kernel_ms(self):
-        """Kernel time of every tile of the last frame (HIP events on the tiles' own streams)."""
+        """Kernel time of every tile of the last frame (HIP events on the tiles' own streams); -1 for a tile that has not
+        rendered.  The calling thread's current device is left as it was."""
         return [p.last_kernel_ms() for p in self.parts]
+
+    def last_warning(self) -> str:
+        """What the last tiled frame went through without failing (peer access unavailable -> staged copies), "" if nothing."""
+        return self._lib.nwe_last_warning(self.parts[0]._ctx).decode()
+
+    def peer_access(self):
+        """Per tile: 1 if its device can write the first device's memory directly (hipDeviceCanAccessPeer; same device = 1),
+        0 if the copy is staged by the runtime, -1 if the query failed."""
+        return [int(self._lib.nwe_debug_peer_access(self.parts[0]._ctx, p._ctx)) for p in self.parts]

@@ -80,7 +80,14 @@ def test_bench_multi_rank_line_rehearsal():
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["steps"] == 1 and d["config"]["frames_per_step"] == 2
     assert d["value"] > 1e7 and abs(d["value"] - 2 * 640000 * 192 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
     assert d["strong"]["ms_per_frame"] > 0 and d["strong"]["kernel_ms_slowest_rank"] > 0
+    assert d["strong"]["gather_ms_slowest_rank"] > 0 and d["strong"]["single_gpu_frame_ms_this_run"] > 0
+    assert 0.5 < d["strong"]["speedup_vs_single_gpu_frame"] < 2.5          # two ranks sharing ONE device: about 1, never 2 x more
+    assert d["rccl"]["world"] == 2 and d["rccl"]["backend"] == "gloo" and len(d["rccl"]["devices"]) == 2
+    assert all(x["device"] and x["cus"] > 0 for x in d["rccl"]["devices"]) and d["rccl"]["distinct_devices"] == 1
     assert "error" not in d["in_process"] and "skipped" not in d["in_process"], d["in_process"]
-    assert d["in_process"]["ms_per_frame"] > 0 and len(d["in_process"]["tile_kernel_ms"]) == 2
+    ip = d["in_process"]
+    assert ip["ms_per_frame"] > 0 and ip["tiles"] == 2 and all(t > 0 for t in ip["tile_kernel_ms"]), ip     # every tile rendered
+    assert ip["peer_access"] == [1, 1] and ip["warning"] == "" and ip["equal_to_single_context_frame"] is True
+    assert "configs" not in d
     assert "cpu_baseline" not in d                                 # rank 0 at N = 1 only
     print("rehearsal line:", {k: d[k] for k in ("value", "ms_per_step")}, d["strong"]["ms_per_frame"], d["in_process"]["ms_per_frame"])

@@ -947,7 +947,13 @@ def test_in_process_tiles_through_the_workspace_call():
         ws.initialize_models(state_dicts=sds)
         got = ws.render_image(0.4, 0.6, 30, 0)
         assert np.array_equal(got, want), devices
-        print("tiles", len(devices), "kernel ms per tile", [round(m, 2) for m in ws.handler.renderer.tile_kernel_ms()])
+        # the frame really went through nwe_render_tiled and EVERY tile rendered (a single-context frame is bit-identical,
+        # so equality alone cannot tell; round 2 shipped exactly that silent fallback)
+        tr = ws.handler.renderer
+        ms = tr.tile_kernel_ms()
+        assert tr.last_tiled and len(ms) == len(devices) and all(m > 0 for m in ms), (devices, ms)
+        assert tr.peer_access() == [1] * len(devices) and tr.last_warning() == ""
+        print("tiles", len(devices), "kernel ms per tile", [round(m, 2) for m in ms])
     # float frames, several poses, depth and acc, non-default size
     init, loc = one.transform_relative_coordinates(0.4, 0.6, 30, 0)
     poses = nwe_amd.get_camera_poses_from_list_of_coordinates(init, [nwe_amd.COORD(yaw=-30.0 * k) for k in range(3)]).numpy()
@@ -956,12 +962,19 @@ def test_in_process_tiles_through_the_workspace_call():
     for k in ("rgb", "depth", "acc"):
         assert torch.equal(a[k], b[k]), k
     assert int(b["flags"].item()) == int(a["flags"].item())
+    assert ws.handler.renderer.last_tiled and all(m > 0 for m in ws.handler.renderer.tile_kernel_ms())
+    # an explicit full range is the whole frame too; a proper row range takes the single-context path and says so
+    c = ws.handler.render_batch(poses, 50, 64, rows=(0, 50))
+    assert ws.handler.renderer.last_tiled and torch.equal(c["rgb"], a["rgb"])
+    d = ws.handler.render_batch(poses, 50, 64, rows=(10, 20))
+    assert not ws.handler.renderer.last_tiled and torch.equal(d["rgb"], a["rgb"][:, 10:20])
     os.environ["NWE_DEVICES"] = "0,0"
     try:
         env = nwe_amd.NeRFReplicaInferenceHandler("office_tokyo", "unused")          # the reference's two-argument construction
         env.initialize_models(state_dicts=sds)
         assert isinstance(env.renderer, nwe_amd.TiledRenderer) and len(env.renderer.parts) == 2
         assert np.array_equal(env.render_coordinates(init, loc), want)
+        assert env.renderer.last_tiled and all(m > 0 for m in env.renderer.tile_kernel_ms())
     finally:
         del os.environ["NWE_DEVICES"]
 
@@ -1072,5 +1085,11 @@ def test_in_process_tiles_edge_cases():
     with pytest.raises(RuntimeError, match="tile 1: .*network not set"):
         broken.render(pose, 3, 40, **kw)
     torch.cuda.synchronize()
+    # last_kernel_ms: the last RENDER launch (create_rays does not count) and the calling thread's device is left alone
+    ms = one.last_kernel_ms()
+    one.create_rays(pose, 3, 40, **kw)
+    assert one.last_kernel_ms() == ms and ms > 0
+    assert tiled.tile_kernel_ms()[3] < 0 and tiled.tile_kernel_ms()[0] > 0      # tiles 3 and 4 of the 3-row frame never rendered
+    assert torch.cuda.current_device() == 0
     for r in (one, tiled, broken):
         r.close()
