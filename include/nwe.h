@@ -226,7 +226,7 @@ int nwe_debug_set_decomposition(nwe_ctx *ctx, int mode);
  * none yet: lets a test check the launcher's choice without timing anything. */
 int nwe_debug_last_plan(const nwe_ctx *ctx);
 
-/* Diagnostic builds only (make -C csrc stamps): DEVICE buffer of 8 uint64 per wave that a -DNWE_STAMPS build of the MFMA
+/* Diagnostic builds only (make -C csrc stamps): DEVICE buffer of 10 uint64 per wave that a -DNWE_STAMPS build of the MFMA
  * kernel fills with s_memtime cycle sums (tools/stamp_run.py); the product build never touches it.  NULL switches it off. */
 int nwe_debug_set_stamps(nwe_ctx *ctx, unsigned long long *per_wave_dev);
 

@@ -247,6 +247,9 @@ __device__ __forceinline__ void mma3(const h8& a_hi, const h8& a_lo, const h8& x
 // left there.  That is sound only while hipcc emits no M0 use of its own in this kernel (it has no reason to on gfx950:
 // no movrel, no GDS, no sendmsg) - tests/test_abi.py::test_kernel_owns_m0 greps the generated assembly for exactly that,
 // and pieces of a group must be issued in order with no other group in between (tile_mma's static schedule does).
+// (An "m0" clobber on the asm statements would say nothing to hipcc: M0 is a reserved register, the clobber is ignored with a
+// warning.  tools/check_m0.py is the guard: every M0 write in the disassembly must be the first line of one of these statements,
+// and no instruction with an implicit M0 operand may appear in the kernel at all.)
 //
 // Timeline (tile T consumes chunk T from buffer T&1; PD = fragment prefetch distance in k-steps):
 //   * ONE barrier per tile, PD k-steps before the tile's end.  Before it every wave waits for its own LDS reads
@@ -878,6 +881,7 @@ __global__ void __launch_bounds__(256) render_mfma_kernel(RenderArgs a_in, NetMf
 #ifdef NWE_STAMPS
     unsigned long long st_enc = 0, st_sync = 0, st_mlp = 0, st_comp = 0;
     const unsigned long long st_begin = __builtin_amdgcn_s_memtime();
+    const unsigned long long st_real = __builtin_amdgcn_s_memrealtime();   // 100 MHz: the in-kernel clock is d(memtime) / d(memrealtime) x 100 MHz
 #endif
     for (int pass = 0; pass < (ni > 0 ? 2 : 1); ++pass) {
         const NetMfma& net = pass == 0 ? nc : nf;
@@ -1108,9 +1112,10 @@ __global__ void __launch_bounds__(256) render_mfma_kernel(RenderArgs a_in, NetMf
     if (flags && a.out.flags) atomicOr(a.out.flags, flags);
 #ifdef NWE_STAMPS
     if (a.stamps && lane == 0) {   // diagnostic build only: a buffer no other code reads
-        unsigned long long* o = a.stamps + ((size_t)blockIdx.x * kWaves + wave) * 8;
+        unsigned long long* o = a.stamps + ((size_t)blockIdx.x * kWaves + wave) * 10;
         o[0] = st_enc; o[1] = st_sync; o[2] = st_mlp; o[3] = st_comp; o[4] = __builtin_amdgcn_s_memtime() - st_begin;
         o[5] = wk.st_pre; o[6] = wk.st_wait; o[7] = wk.st_post;
+        o[8] = __builtin_amdgcn_s_memrealtime() - st_real; o[9] = st_begin;
     }
 #endif
 }

@@ -317,7 +317,7 @@ def to8b(x: np.ndarray) -> np.ndarray:
 
 
 # --------------------------------------------------------------------------
-# poses  (utils/camera_poses.py) -- closed-form Rodrigues, parity unpinned (no cv2 here)
+# poses  (utils/camera_poses.py) -- cv2.Rodrigues restated after OpenCV's published algorithm, parity unpinned (no cv2 here)
 # --------------------------------------------------------------------------
 
 
@@ -335,14 +335,25 @@ def _euler_c2w(x, y, z, yaw, pitch, roll) -> np.ndarray:
     return R_roll @ R_pitch @ R_yaw @ T
 
 
+def rodrigues_matrix(rvec) -> np.ndarray:
+    """cv2.Rodrigues(rvec)[0] for a 3-vector, after the algorithm OpenCV documents (calib3d, cv::Rodrigues), float64:
+    theta = |r|; R = I for theta < DBL_EPSILON, else with k = r/theta: R = cos(theta) I + (1 - cos(theta)) k k^T + sin(theta) K,
+    K the cross-product matrix of k.  (Written with outer/cross products; nwe_amd/camera_poses.py writes the entries out.)"""
+    r = np.array(rvec, dtype=np.float64).reshape(3)
+    theta = math.sqrt(float(r @ r))
+    if theta < 2.220446049250313e-16:
+        return np.eye(3)
+    k = r * (1.0 / theta)
+    K = np.array([[0.0, -k[2], k[1]], [k[2], 0.0, -k[0]], [-k[1], k[0], 0.0]])
+    return math.cos(theta) * np.eye(3) + (1.0 - math.cos(theta)) * np.outer(k, k) + math.sin(theta) * K
+
+
 def camera_pose(init, coord) -> torch.Tensor:
     """(init COORD, local COORD) -> [1,4,4] fp32.  utils/camera_poses.py:52-75.  `init`/`coord` are
-    6-tuples (x, y, z, yaw, pitch, roll) in degrees.  cv2.Rodrigues([0,0,a]) == Rz(a) and
-    cv2.Rodrigues([a,0,0]) == Rx(a) exactly in form; evaluated here in float64 as OpenCV does."""
+    6-tuples (x, y, z, yaw, pitch, roll) in degrees."""
     ext = _euler_c2w(*init)
-    a, b = coord[3] / 180.0 * np.pi, coord[4] / 180.0 * np.pi
-    Rz = np.array([[math.cos(a), -math.sin(a), 0], [math.sin(a), math.cos(a), 0], [0, 0, 1]], dtype=np.float64)
-    Rx = np.array([[1, 0, 0], [0, math.cos(b), -math.sin(b)], [0, math.sin(b), math.cos(b)]], dtype=np.float64)
+    Rz = rodrigues_matrix([0.0, 0.0, coord[3] / 180.0 * np.pi])       # camera_poses.py:62
+    Rx = rodrigues_matrix([coord[4] / 180.0 * np.pi, 0.0, 0.0])       # :63
     ext[:3, :3] = Rz @ Rx @ ext[:3, :3]                               # camera_poses.py:66-69
     return torch.tensor(np.asarray([ext], dtype=np.float32).reshape(-1, 4, 4))
 

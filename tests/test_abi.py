@@ -132,3 +132,17 @@ def test_header_is_usable_from_plain_c(tmp_path):
                     "-o", str(exe), "-L", libdir, "-lnwe_hip", "-lm", f"-Wl,-rpath,{libdir}"], check=True)
     out = subprocess.run([str(exe)], capture_output=True, text=True)
     assert out.returncode == 0 and "abi_smoke ok" in out.stdout, out.stderr
+
+
+def test_host_code_under_sanitizers():
+    """`make asan`: the HOST half of nwe_abi.hip (validation, the fp32 and MFMA packers with the fp64 fold, the copies out)
+    built with AddressSanitizer + UndefinedBehaviorSanitizer and driven by tests/c/abi_smoke.c on a host-only context.  GPU
+    sanitizers do not exist on this pool; the device code is covered by the parity tests."""
+    import shutil
+    import subprocess
+    if not shutil.which("hipcc") and not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("no hipcc in this environment")
+    csrc = os.path.join(ROOT, "nerf-workspaces-explorer_amd", "csrc")
+    out = subprocess.run(["make", "-C", csrc, "asan"], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "abi_smoke ok" in out.stdout, (out.stdout[-1500:], out.stderr[-3000:])
+    assert "AddressSanitizer" not in out.stderr and "runtime error" not in out.stderr

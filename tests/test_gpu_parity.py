@@ -210,7 +210,7 @@ def test_c3_subset_against_golden(r_c3, golden_dir, precision, pose):
           f"{np.median(dcdf):.1e} max {dcdf.max():.1e}; amplification median {np.median(amp):.0f} max {amp.max():.0f}; "
           f"max dz/bound {np.max(dz / bound):.2f}; switch-adjacent rays {int(near_switch.sum())}; unexplained {int(unexplained.sum())}")
     assert not unexplained.any()
-    assert near_switch.sum() <= 8
+    assert near_switch.sum() <= 2                                                        # measured: 0
     # T3 ------------------------------------------------------------------------------------------
     sf = _t(_sd(1001, 8, 256))
     fo = O.fine_pass_given_depths(rays_cpu, z, sf, O.RenderConfig())
@@ -242,8 +242,89 @@ def test_c3_subset_against_golden(r_c3, golden_dir, precision, pose):
     assert err[same_depths].max() <= RGB_TOL                  # every ray sampled where the reference sampled it
     assert not (moved & (dz <= 2e-5) & ~cliff_g & ~cliff).any()   # a ray above tolerance has moved depths, explained in T2b
     assert psnr(rgb, g[f"rgb_fine_{pose}"]) > 50
-    assert np.median(err) < 2e-6 and moved.mean() < 0.03 and err.max() < 5e-3
+    assert np.median(err) < 2e-6 and moved.mean() < 0.012 and err.max() < 1.5e-3      # measured: 0.46-0.71 % of the rays, max 6.1e-4
     assert cliff_g.sum() <= 8 and cliff_c.sum() <= 8
+
+
+def _rays_at_points(pts, dirs):
+    """Rays whose every sample sits exactly at `pts`: o = pts, near = far = 0 (z = 0*(1-t) + 0*t = 0, point = o + d*0 = o),
+    view direction column = dirs as given (handler.py:210-214 takes it from the ray, it is not re-normalised)."""
+    n = pts.shape[0]
+    return torch.from_numpy(np.concatenate([pts, dirs, np.zeros((n, 2), np.float32), dirs], 1).astype(np.float32)).cuda()
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+@pytest.mark.parametrize("tag,D,Wn,seed", [("4x128", 4, 128, 1000), ("8x256", 8, 256, 1001)])
+def test_reference_mlp_vectors_through_the_kernels(golden_dir, precision, tag, D, Wn, seed):
+    """tests/golden/mlp.npz (the reference's NeRFModel on 512 rows of [gamma(pts), gamma(dirs)], embed.npz's points incl.
+    |x| ~ 20, -0.0, 1e-8: top-band arguments ~1000 rad) through the HIP kernels: Embedding + NeRFModel in isolation on
+    reference-generated inputs (embedding.py:44-48, nerf_model.py:45-83).  Both decompositions of the MFMA kernel."""
+    ge, gm = np.load(os.path.join(golden_dir, "embed.npz")), np.load(os.path.join(golden_dir, "mlp.npz"))
+    x, y = gm[f"x_{tag}"], gm[f"y_{tag}"]
+    enc = np.concatenate([ge["enc_xyz"], ge["enc_dir"]], 1)
+    assert np.array_equal(x, np.concatenate([enc, enc], 0))          # the fixture's rows ARE gamma of embed.npz's points, twice
+    rays = _rays_at_points(np.concatenate([ge["pts"]] * 2, 0), np.concatenate([ge["dirs"]] * 2, 0))
+    assert float(np.abs(ge["pts"]).max()) > 15.0                      # the edge inputs are in there
+    r = nwe_amd.Renderer(0)
+    r.set_network(0, _sd(seed, D, Wn))
+    r.set_sampling(2, 0)
+    try:
+        for mode in ((0, 1) if precision != "f32" else (-1,)):
+            r.debug_set_decomposition(mode)
+            raw = r.render_rays(rays, precision=precision, outputs=("raw_coarse",))["raw_coarse"].cpu().numpy()
+            err = np.abs(raw - y[:, None, :])
+            far_rows = np.abs(np.concatenate([ge["pts"]] * 2, 0)).max(-1) > 15.0
+            print(f"[{precision} {tag} mode {mode}] raw vs reference NeRFModel: max {err.max():.2e}, on the |x| > 15 rows {err[far_rows].max():.2e}, "
+                  f"|y| max {np.abs(y).max():.2f}")
+            assert err.max() <= 5e-6
+            assert np.array_equal(raw[:, 0], raw[:, 1])               # both samples sit at the same point
+    finally:
+        r.close()
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+def test_reference_embedding_vectors_through_the_kernels(golden_dir, precision):
+    """tests/golden/embed.npz through the kernels' positional encoding, component by component: a probe network carries ONE
+    component of gamma(x) (or gamma(d)) unchanged to an output - layer 0 (resp. the view layer) selects it and adds 3 so that
+    every ReLU is the identity, the other layers are identity matrices, the sigma (resp. red) head subtracts the 3 - and the
+    output must be the reference's Embedding value (embedding.py:44-48) within 2e-6 at every point, |x| ~ 20 included."""
+    ge = np.load(os.path.join(golden_dir, "embed.npz"))
+    rays = _rays_at_points(ge["pts"], ge["dirs"])
+    D, Wn = 4, 128
+    shapes = nwe_amd.synthetic.layer_shapes(D, Wn, skips=())
+    r = nwe_amd.Renderer(0)
+    r.set_sampling(2, 0)
+    worst = 0.0
+    try:
+        for comp in list(range(63)) + [63 + j for j in range(27)]:
+            sd = {}
+            for name, (n_out, n_in) in shapes.items():
+                sd[name + ".weight"] = np.zeros((n_out, n_in), np.float32)
+                sd[name + ".bias"] = np.zeros((n_out,), np.float32)
+            for i in range(1, D):
+                sd[f"_pts_linears.{i}.weight"][:] = np.eye(Wn, dtype=np.float32)
+            sd["_feature_linear.weight"][:] = np.eye(Wn, dtype=np.float32)
+            if comp < 63:           # gamma(x)[comp] -> h[0] -> sigma
+                sd["_pts_linears.0.weight"][0, comp] = 1.0
+                sd["_pts_linears.0.bias"][0] = 3.0
+                sd["_alpha_linear.weight"][0, 0] = 1.0
+                sd["_alpha_linear.bias"][0] = -3.0
+                col = 3
+            else:                   # gamma(d)[comp - 63] -> view layer output 0 -> red
+                sd["_views_linears.0.weight"][0, Wn + comp - 63] = 1.0
+                sd["_views_linears.0.bias"][0] = 3.0
+                sd["_rgb_linear.weight"][0, 0] = 1.0
+                sd["_rgb_linear.bias"][0] = -3.0
+                col = 0
+            r.set_network(0, sd)
+            raw = r.render_rays(rays, precision=precision, outputs=("raw_coarse",))["raw_coarse"].cpu().numpy()[:, 0, col]
+            want = ge["enc_xyz"][:, comp] if comp < 63 else ge["enc_dir"][:, comp - 63]
+            e = float(np.abs(raw - want).max())
+            worst = max(worst, e)
+            assert e <= 2e-6, (comp, e)
+    finally:
+        r.close()
+    print(f"[{precision}] gamma(x), gamma(d) of embed.npz through the kernel, all 90 components: max err {worst:.2e}")
 
 
 @pytest.mark.parametrize("precision", ["f32", "f16x3"])

@@ -63,9 +63,47 @@ def test_pose_helper_closed_forms():
         R = p[k, :3, :3].double().numpy()
         np.testing.assert_allclose(R @ R.T, np.eye(3), atol=1e-6)
         assert np.array_equal(p[k, :3, 3].numpy(), p[0, :3, 3].numpy())            # local turns keep the position
-    # the oracle's independent restatement agrees bit for bit
-    ref = O.camera_pose(tuple(init), (0, 0, 0, -30.0, 0.0, 0.0))
-    assert torch.equal(ref[0], p[1])
+
+
+def test_rodrigues_general_form_against_the_axis_closed_forms():
+    """utils/camera_poses.py:62-63 calls cv2.Rodrigues on [0, 0, yaw] and [pitch, 0, 0].  cv2 is absent (parity against its
+    binary is unpinned); the product and the oracle each restate OpenCV's published GENERAL algorithm, and for these
+    axis-aligned vectors it must give Rz / Rx.  Checked after the float32 cast of the pose (camera_poses.py:69), on the GUI's
+    30-degree grid (application/app.py:198, workspace.py:99-100) and on random angles; and the general form is a rotation
+    about the given axis by |r| for arbitrary vectors."""
+    from nwe_amd.camera_poses import camera_to_world, rodrigues
+    C = nwe_amd.COORD
+    init = C(x=0.0, y=-0.5, z=-0.75 / np.cos(-10 / 180 * np.pi), pitch=-90.0)
+    rng = np.random.default_rng(5)
+    grid = [(-30.0 * h, 30.0 * v) for h in range(-12, 13) for v in range(-3, 4)]
+    rand = [tuple(x) for x in rng.uniform(-720.0, 720.0, size=(500, 2))] + [(1e-9, -1e-9), (0.0, 0.0), (360.0, -360.0)]
+    worst = 0.0
+    for yaw, pitch in grid + rand:
+        a, b = yaw / 180.0 * np.pi, pitch / 180.0 * np.pi
+        rz = np.array([[math.cos(a), -math.sin(a), 0.0], [math.sin(a), math.cos(a), 0.0], [0.0, 0.0, 1.0]])
+        rx = np.array([[1.0, 0.0, 0.0], [0.0, math.cos(b), -math.sin(b)], [0.0, math.sin(b), math.cos(b)]])
+        want = camera_to_world(init).reshape(4, 4)
+        want[:3, :3] = rz @ rx @ want[:3, :3]                                       # closed forms, float32 on assignment
+        got = nwe_amd.get_camera_poses_from_list_of_coordinates(init, [C(yaw=yaw, pitch=pitch)])[0].numpy()
+        ora = O.camera_pose(tuple(init), (0, 0, 0, yaw, pitch, 0.0))[0].numpy()
+        # the double results agree to ~1e-16 (r * (1/|r|) need not be exactly 1), so the float32 poses are equal except where
+        # that last bit decides a rounding: allow one float32 ulp, count exact equality
+        worst = max(worst, float(np.abs(got - want).max()), float(np.abs(ora - want).max()))
+        assert np.abs(got - want).max() <= 6e-8 and np.abs(ora - want).max() <= 6e-8, (yaw, pitch)
+        np.testing.assert_allclose(rodrigues([0, 0, a]), rz, atol=3e-16)
+        np.testing.assert_allclose(O.rodrigues_matrix([b, 0, 0]), rx, atol=3e-16)
+    assert worst <= 6e-8
+    on_grid = [np.array_equal(nwe_amd.get_camera_poses_from_list_of_coordinates(init, [C(yaw=y, pitch=p_)])[0].numpy(),
+                              O.camera_pose(tuple(init), (0, 0, 0, y, p_, 0.0))[0].numpy()) for y, p_ in grid]
+    assert all(on_grid)                                                              # product == oracle bit for bit on the GUI grid
+    for _ in range(50):                                                              # arbitrary vectors: a proper rotation about r by |r|
+        r = rng.normal(size=3) * rng.uniform(0.01, 4.0)
+        R = rodrigues(r)
+        np.testing.assert_allclose(R, O.rodrigues_matrix(r), atol=1e-15)
+        np.testing.assert_allclose(R @ R.T, np.eye(3), atol=1e-14)
+        np.testing.assert_allclose(R @ r, r, atol=1e-14)
+        assert abs(np.trace(R) - (1 + 2 * math.cos(np.linalg.norm(r)))) < 1e-13 and np.linalg.det(R) > 0.999999
+    assert np.array_equal(rodrigues([0, 0, 1e-17]), np.eye(3))                       # theta < DBL_EPSILON -> identity
 
 
 def test_checkpoint_format_roundtrip(tmp_path):
