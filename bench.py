@@ -318,6 +318,9 @@ def main() -> None:
                          "frac": achieved / PEAK_F16_TFLOPS,
                          "traffic": traffic, "traffic_note": traffic_note + "; algorithmic 1.76e7 B per launch (poses in, weights once, rgb/depth/acc out)",
                          "kernel": ("render_mfma_kernel<256,8,4,%s>" % ("unfolded" if args.unfolded else "folded")) if args.precision != "f32" else "render_f32_kernel",
+                         "launch_plan": r0.debug_last_plan(),
+                         "launch_plan_note": "0 = one launch of 4-packet workgroups; 2 = the full rounds of workgroups as packets + the ragged last "
+                                             "round sample-split in a second launch of the same kernel template right behind it; kernel_ms covers both",
                          "kernel_ms": k_ms, "algorithmic_flops_per_launch": flops_per_launch,
                          "executed_mfma_passes": passes, "mfma_per_eval_and_pass": mfma_per_eval,
                          "executed_mfma_tflops": exec_tflops,

@@ -392,7 +392,22 @@ struct DmaPlan {
     static constexpr int TOT = REST > 0 ? REST + 2 : 0;                                   // logical slots: pieces, then the two extras
     static constexpr int PPK = TOT == 0 ? 0 : (TOT + (QSYNC > 0 ? QSYNC : 1) - 1) / (QSYNC > 0 ? QSYNC : 1);   // slots per k-step (1 on long tiles)
     static_assert(TOT == 0 || QSYNC > 0, "no k-step in front of the barrier for the DMA pieces");
-    static constexpr int lo(int q) { return q * PPK < TOT ? q * PPK : TOT; }
+    // A piece holds the wave's issue for ~30 cycles whatever else the gap carries, and two pieces three MFMAs apart cost more
+    // than twice one piece six MFMAs apart (tools/ubench/dma_cost.hip: 20 vs 8.6 cycles each beside 32x32x16 MFMAs), so where
+    // the tile is long enough the pieces go out every SECOND k-step: the last one still MARGIN k-steps (~500 cycles, more than
+    // an L2-hit LDS-DMA takes to land) in front of the barrier that waits for it; the two extra slots follow back to back.
+#ifndef NWE_DMA_STRIDE
+#define NWE_DMA_STRIDE 2
+#endif
+    static constexpr int MARGIN = 5;
+    static constexpr int STRIDE = (NWE_DMA_STRIDE == 2 && PPK == 1 && 2 * (REST - 1) <= QSYNC - MARGIN && 2 * (REST - 1) + 2 <= QSYNC - 1) ? 2 : 1;
+    static constexpr int kstep_of(int j) { return STRIDE == 1 ? j / (PPK > 0 ? PPK : 1) : (j < REST ? 2 * j : 2 * (REST - 1) + 1 + (j - REST)); }
+    static constexpr int lo(int q) {                                                      // slots issued before k-step q
+        int n = 0;
+        for (int j = 0; j < TOT; ++j) n += kstep_of(j) < q ? 1 : 0;
+        return n;
+    }
+    static_assert(TOT == 0 || lo(QSYNC) == TOT, "every slot must be issued in front of the barrier");
     static constexpr uint32_t mask() {
         uint32_t m = 0;
         for (int q = 0; q < NQ; ++q) {
@@ -1160,9 +1175,10 @@ bool launch_t(const RenderArgs& a, const NetMfma& nc, const NetMfma& nf, bool th
     const double t_packet = rounds(a.n_rays, rays_wg) * its;
     const double t_split = rounds(a.n_rays, kRaysPerWave) * its_split;
     const double t_hybrid = full > 0 && full < a.n_rays ? (double)(full / rays_wg / cus) * its + rounds(a.n_rays - full, kRaysPerWave) * its_split : 1e300;
-    // two launches only when they buy at least 3 % (one launch per frame keeps profiles simple: 800x800 would gain 1 %)
+    // two launches when the model promises at least 0.8 %: the 800x800 frame (19 full rounds + 136 workgroups) is 1.0 % by the
+    // model and measures -0.4 % (368.4 vs 370.0 ms, alternating, tools/plan_ab.py); a second launch costs a few microseconds
     const double t_single = t_packet <= t_split ? t_packet : t_split;
-    int plan = t_hybrid < 0.97 * t_single ? 2 : (t_packet <= t_split ? 0 : 1);
+    int plan = t_hybrid < 0.992 * t_single ? 2 : (t_packet <= t_split ? 0 : 1);
     if (decomposition >= 0) plan = decomposition;   // nwe_debug_set_decomposition: tests force one
     if (a.n_samples > kPacketMaxSamples) plan = 1;  // only the single-packet workgroup has LDS for that many coarse weights
     if (plan_out) *plan_out = plan;

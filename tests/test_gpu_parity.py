@@ -767,13 +767,13 @@ def test_hybrid_launch_plan(r_c3):
     print("kernel ms by plan (packets, split, hybrid, auto):", [round(ms[m], 2) for m in (0, 1, 2, -1)])
 
     def model(n_rays, cus=256, ns=64, ni=128):
-        """launch_t's cost model: rounds of workgroups x sample iterations; two launches only for a gain of >= 3 %."""
+        """launch_t's cost model: rounds of workgroups x sample iterations; two launches for a modelled gain of >= 0.8 %."""
         rounds = lambda rays, per: -(-(-(-rays // per)) // cus)
         its, its_split = ns + ns + ni, 1.06 * ((ns + 3) // 4 + (ns + ni + 3) // 4)
         full = n_rays // 128 // cus * cus * 128
         t_p, t_s = rounds(n_rays, 128) * its, rounds(n_rays, 32) * its_split
         t_h = full // 128 // cus * its + rounds(n_rays - full, 32) * its_split if 0 < full < n_rays else float("inf")
-        return 2 if t_h < 0.97 * min(t_p, t_s) else (0 if t_p <= t_s else 1)
+        return 2 if t_h < 0.992 * min(t_p, t_s) else (0 if t_p <= t_s else 1)
 
     cus = torch.cuda.get_device_properties(0).multi_processor_count
     assert r_c3.debug_last_plan() == model(200 * 300, cus)
@@ -933,7 +933,8 @@ def test_c4_full_size_row_tiles_equal_the_frame(r_c3):
     kw = dict(fx=fx, fy=fy, cx=cx, cy=cy, near=0.1, far=10.0, outputs=("rgb", "depth", "acc"))
     whole = r_c3.render(pose, 800, 800, **kw)
     t_whole = r_c3.last_kernel_ms()
-    assert r_c3.debug_last_plan() == 0          # 5000 workgroups of four packets: one launch
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    assert cus != 256 or r_c3.debug_last_plan() == 2   # 5000 workgroups = 19 full rounds as packets + 17 408 rays sample-split (1 % by the model)
     tiles, ms = [], []
     for rr in shard_rows(800, 8):
         tiles.append(r_c3.render(pose, 800, 800, rows=rr, **kw))

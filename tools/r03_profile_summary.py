@@ -34,10 +34,14 @@ def main():
     stats = glob.glob(f"{OUT}/r03_prof/**/*kernel_stats.csv", recursive=True)
     if stats:
         shutil.copy(stats[0], os.path.join(PROF, "r03_kernel_stats.csv"))
+        per_frame = 0.0
         for r in csv.DictReader(open(stats[0])):
             if "render_mfma" in r["Name"]:
                 lines.append(f"kernel trace: {r['Name'][:70]}: calls {r['Calls']}, average {float(r['AverageNs']) / 1e6:.2f} ms, "
                              f"{r['Percentage']} % of GPU time")
+                per_frame += float(r["AverageNs"]) / 1e6
+        lines.append(f"kernel trace: a frame = one launch of each of the render_mfma instantiations above (packets for the full rounds of "
+                     f"workgroups + sample split for the ragged last round): {per_frame:.2f} ms per frame")
     for name in ("r03_bench_under_rocprof.json", "r03_bench.json"):
         if os.path.exists(os.path.join(OUT, name)):
             shutil.copy(os.path.join(OUT, name), os.path.join(PROF, name))
