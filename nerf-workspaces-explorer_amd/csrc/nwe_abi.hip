@@ -22,7 +22,8 @@ struct NetState {
     bool mfma_ok = false;
     bool folded = false;           // MFMA stream: _feature_linear multiplied into the view layer
     std::vector<uint8_t> stream;   // MFMA kernel: 1-KiB tiles in consumption order
-    std::vector<float> bias_tab;   // MFMA kernel: 32 floats per chunk
+    std::vector<float> bias_tab;   // MFMA kernel: 32 floats per chunk, then (folded) the dot rows of _alpha_linear
+    int n_chunks = 0;              // chunks of the stream = bias rows in front of the dot rows
     float w_scale = 1.f;           // power of two the packed weights are multiplied by
     NetMfma mf = {};
     uint8_t* d_stream = nullptr;
@@ -200,7 +201,7 @@ void pack_mfma(NetState& n, const float* const* w, const float* const* b) {
     const int in_dims[4] = {W + n.in_dir, W, W, W / 2}, out_dims[4] = {W / 2, W, 1, 3};
     double wmax = 0.0;
     for (int li = 0; li < D + 4; ++li) {
-        if (n.folded && (li == iv || li == ife)) continue;
+        if (n.folded && (li == iv || li == ife || li == ia)) continue;   // folded: multiplied out / evaluated in fp32 (dot rows)
         const size_t cnt = li < D ? (size_t)W * (li == 0 ? n.in_xyz : (li == n.skip + 1 ? W + n.in_xyz : W))
                                   : (size_t)in_dims[li - D] * out_dims[li - D];
         for (size_t k = 0; k < cnt; ++k) wmax = std::max(wmax, (double)std::fabs(w[li][k]));
@@ -218,8 +219,10 @@ void pack_mfma(NetState& n, const float* const* w, const float* const* b) {
         if (i == n.skip + 1) layer(i, W, W + n.in_xyz, W / 32, 0, {{1, 4, 0}, {0, KH, n.in_xyz}});   // cat([pts, h]), nerf_model.py:59
         else layer(i, W, W, W / 32, 0, {{0, KH, 0}});
     }
-    if (!n.folded) layer(ife, W, W, W / 32, 0, {{0, KH, 0}});
-    layer(ia, 1, W, 1, 1, {{0, KH, 0}});
+    if (!n.folded) {
+        layer(ife, W, W, W / 32, 0, {{0, KH, 0}});
+        layer(ia, 1, W, 1, 1, {{0, KH, 0}});
+    }
     if (n.folded) {
         RowMap rows{W / 2, 0};
         for (int rt = 0; rt < W / 64; ++rt) put_chunk(n, wv.data(), bv.data(), W + n.in_dir, rows, rt, {{0, KH, 0}, {2, 2, W}});
@@ -227,6 +230,15 @@ void pack_mfma(NetState& n, const float* const* w, const float* const* b) {
         layer(iv, W / 2, W + n.in_dir, W / 64, 0, {{0, KH, 0}, {2, 2, W}});                           // cat([feature, views]), :66
     }
     layer(irgb, 3, W / 2, 1, 1, {{0, KH / 2, 0}});
+    n.n_chunks = (int)(n.bias_tab.size() / 32);
+    if (n.folded) {
+        // _alpha_linear (nerf_model.py:63) is not a tile of the folded stream: the kernel accumulates sigma = w . h + b in fp32
+        // with the epilogues of the last trunk layer's tiles.  Row rt of the dot table = the weights of trunk features
+        // 32 rt .. 32 rt + 31 (the row order of that layer's tile rt, like its bias row), then one row with the bias in front.
+        for (int k = 0; k < W; ++k) n.bias_tab.push_back(w[ia][k]);
+        n.bias_tab.push_back(b[ia][0]);
+        n.bias_tab.resize(n.bias_tab.size() + 31, 0.f);
+    }
 }
 
 void pack_f32(NetState& n, const float* const* w, const float* const* b) {
@@ -420,7 +432,7 @@ int nwe_set_network(nwe_ctx* c, int which, int depth, int width, int in_xyz, int
     n.mf = {};
     n.mf.D = depth; n.mf.W = width; n.mf.skip = skip_layer; n.mf.folded = n.folded ? 1 : 0;
     n.mf.n_tiles = (int)(n.stream.size() / kTileBytes);
-    n.mf.n_chunks = (int)(n.bias_tab.size() / 32);
+    n.mf.n_chunks = n.mfma_ok ? n.n_chunks : 0;
     n.mf.inv_scale = 1.f / n.w_scale;
     if (!c->host_only) {
         DeviceGuard guard;

@@ -25,7 +25,8 @@ void launch_render_f32(const RenderArgs& a, const NetF32& nc, const NetF32& nf, 
 // ---- MFMA kernel: a stream of 1-KiB tiles in consumption order (DESIGN.md "weight stream") -----
 struct NetMfma {
     const uint8_t* stream;  // device: 1-KiB tiles, (hi, lo) per k-step, chunk after chunk
-    const float* bias;      // device: 32 floats per chunk (tile row i -> bias of the weight row it holds)
+    const float* bias;      // device: 32 floats per chunk (tile row i -> bias of the weight row it holds); folded: then W/32 + 1 dot
+                            // rows (the weights of _alpha_linear in the row order of the last trunk layer's tiles, and its bias)
     int n_tiles, n_chunks;
     float inv_scale;        // weights are stored multiplied by 1/inv_scale (a power of two)
     int D, W, skip;

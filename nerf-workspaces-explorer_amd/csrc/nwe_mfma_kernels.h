@@ -58,7 +58,12 @@ struct Shape {
     static constexpr int N_RGB = 2 * KV / kWaves;
     static constexpr int CHUNK_BYTES = N_S * kWaves * kTileBytes;
     static constexpr int N_CHUNKS = NT + D * NT + 1 + NTV + 1;   // layer 0, D-1 trunk layers + feature, alpha, views, rgb (unfolded: the larger count)
-    static constexpr int N_CHUNKS_FOLDED = N_CHUNKS - NT;        // _feature_linear folded into the view layer at pack time
+    // FOLD (the product path): _feature_linear is folded into the view layer at pack time (-NT chunks) and _alpha_linear is not
+    // a tile of the stream at all (-1): its single output row is a dot product with the last trunk layer's activations,
+    // accumulated in fp32 on the vector ALU inside that layer's epilogue (see mlp_eval).  Its weights travel as NT extra
+    // rows of the bias table (row rt, element i = weight of trunk feature 32 rt + i) plus one row whose element 0 is its bias.
+    static constexpr int N_CHUNKS_FOLDED = N_CHUNKS - NT - 1;
+    static constexpr int N_DOT_ROWS = NT + 1;
     // A LONG chunk (>= 16 k-steps, three-pass mode) keeps the (hi, lo) tiles of its last k-step in a rotating tail slot
     // instead of the chunk buffer, see Walker.
     static constexpr int LONG_PIECES = 8;
@@ -85,10 +90,11 @@ typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 // Epilogue of a pending tile: v = max(acc/scale + bias, lower), hi = fp16(v), lo = fp16(v - hi); register r of the tile
 // is element r&7 of the (r>>3)-th of its two output k-steps.  This is the FALLBACK form, one element per call (every
 // second call packs a pair), used only by tiles too short for the staged plan below (EpiPlan::STAGED == false).
-template <bool X3>
+template <bool X3, bool DOT = false>
 __device__ __forceinline__ void finish_elem(const Pend& t, int e, float inv_scale, float lower, float& keep, h8& hi0, h8& lo0,
-                                            h8& hi1, h8& lo1) {
+                                            h8& hi1, h8& lo1, const float* dotw = nullptr, float* dot = nullptr) {
     const float v = fmaxf(pend_value(t, e, inv_scale), lower);
+    if (DOT) *dot = __builtin_fmaf(dotw[8 * (e >> 2) + (e & 3)], v, *dot);   // dotw already points at this lane half's rows
     if ((e & 1) == 0) { keep = v; return; }
     const float v0 = keep, v1 = v;
     h2 hp;
@@ -119,6 +125,7 @@ struct Epi {
     float r[16];        // residual v - hi
     uint32_t hp[8];     // packed fp16 pairs: hi
     uint32_t lp[8];     // lo
+    float dw[16];       // DOT tiles: the dot-product weights of the elements (read one stage ahead of their use)
 };
 
 // PM: bit q set = k-step q issues a DMA piece.  A piece costs ~16 issue cycles (it is priced like a four-dword store),
@@ -156,10 +163,34 @@ __device__ __forceinline__ h8 pack4(uint32_t a, uint32_t b, uint32_t c, uint32_t
 }
 
 // Stage ST of group G of the plan.
-template <class P, bool X3, int G, int ST>
-__device__ __forceinline__ void epi_stage(const Pend& t, Epi& E, float inv_scale, float lower, h8& y0h, h8& y0l, h8& y1h, h8& y1l) {
+// DOT: the tile's activations also feed a one-row linear layer (_alpha_linear on the last trunk layer's output): dot +=
+// w[row] * v for every element, in fp32 on the vector ALU.  The weights of a group (dotw: this tile's row of the table in
+// LDS, laid out like a bias row) are read in the group's fma stage and used one per later stage, so that the chain of
+// dependent FMAs on `dot` never has two links in one MFMA gap.
+template <class P, bool X3, int G, int ST, bool DOT>
+__device__ __forceinline__ void epi_stage(const Pend& t, Epi& E, float inv_scale, float lower, h8& y0h, h8& y0l, h8& y1h, h8& y1l,
+                                          const float* dotw, float& dot) {
     constexpr int st = ST, e0 = G * P::GS;
     constexpr int ST_PACK = 3, ST_RES = 4, ST_PACKLO = 5, ST_PARK = X3 ? 6 : 4;
+    if constexpr (DOT) {
+        static_assert(P::NS - ST_PACK >= 1, "no stage left for the dot product");
+        constexpr int NDS = P::NS - ST_PACK;                       // stages that carry dot FMAs: ST_PACK .. NS-1
+        if (st == 1) {
+#pragma unroll
+            for (int q = e0 / 4; q < (e0 + P::GS) / 4; ++q) {      // elements 4q..4q+3 = rows 8q + 4h + 0..3 (like Pend::bias)
+                const float4 w4 = *reinterpret_cast<const float4*>(dotw + 8 * q);
+                E.dw[4 * q] = w4.x; E.dw[4 * q + 1] = w4.y; E.dw[4 * q + 2] = w4.z; E.dw[4 * q + 3] = w4.w;
+            }
+        }
+        if (st >= ST_PACK) {
+#pragma unroll
+            for (int e = e0; e < e0 + P::GS; ++e)
+                if ((e - e0) % NDS == st - ST_PACK) {
+                    dot = __builtin_fmaf(E.dw[e], E.v[e], dot);
+                    asm volatile("" : "+v"(dot));   // HERE: the sum is only read at the end of the evaluation, and without a use LLVM
+                }                                   // sinks every FMA (and keeps every activation alive) down to it
+        }
+    }
     if (st == 0) {
 #pragma unroll
         for (int e = e0; e < e0 + P::GS; ++e) {
@@ -219,10 +250,11 @@ __device__ __forceinline__ void epi_stage(const Pend& t, Epi& E, float inv_scale
 }
 
 // Gap GI (0-based over the tile's main k-steps) of the plan: the stage of one group, or nothing.
-template <class P, bool X3, int GI>
-__device__ __forceinline__ void epi_gap(const Pend& t, Epi& E, float inv_scale, float lower, h8& y0h, h8& y0l, h8& y1h, h8& y1l) {
+template <class P, bool X3, int GI, bool DOT>
+__device__ __forceinline__ void epi_gap(const Pend& t, Epi& E, float inv_scale, float lower, h8& y0h, h8& y0l, h8& y1h, h8& y1l,
+                                        const float* dotw, float& dot) {
     constexpr int slot = P::slot_at(GI);
-    if constexpr (slot >= 0) epi_stage<P, X3, slot / P::NS, slot % P::NS>(t, E, inv_scale, lower, y0h, y0l, y1h, y1l);
+    if constexpr (slot >= 0) epi_stage<P, X3, slot / P::NS, slot % P::NS, DOT>(t, E, inv_scale, lower, y0h, y0l, y1h, y1l, dotw, dot);
 }
 
 template <bool X3>
@@ -427,10 +459,17 @@ struct DmaPlan {
 // head), which sets the plan's deadline.  DMA (DmaPlan): this tile issues the pieces [PD, NB) (+2 if extraB) of chunk
 // T+1 in its first k-steps and, after its barrier, pieces [0, min(PD, NA)) of chunk T+2 (NA pieces per wave, +2 if
 // extraA; NA = 0: none).  HASNEXT: a tile follows in this pass (its first fragments are prefetched).
-template <int NKP, int NKH, int NKD, int PHASE, bool X3, bool PEND, int NB, int NA, bool HASNEXT, bool FEEDS = false, class WalkerT>
+// DOT: the pending tile's epilogue also accumulates the dot product of its activations with the row `dot_row` of the dot table
+// (32 floats in LDS, see epi_stage) into *dot.
+template <int NKP, int NKH, int NKD, int PHASE, bool X3, bool PEND, int NB, int NA, bool HASNEXT, bool FEEDS = false, bool DOT = false, class WalkerT>
 __device__ __forceinline__ void tile_mma(WalkerT& wk, Frags& F, int lane, bool use_g, bool extraB, bool extraA, const h8* Ghi,
                                          const h8* Glo, const h8* Xhi, const h8* Xlo, const h8* Dhi, const h8* Dlo, Pend& cur,
-                                         const Pend& prev, float inv_scale, float lower, h8& y0h, h8& y0l, h8& y1h, h8& y1l, int na_override = -1) {
+                                         const Pend& prev, float inv_scale, float lower, h8& y0h, h8& y0l, h8& y1h, h8& y1l, int na_override = -1,
+                                         const float* dot_row = nullptr, float* dot = nullptr) {
+    static_assert(!DOT || PEND, "a dot product rides on a pending tile's epilogue");
+    float dot_dummy = 0.f;
+    float& dot_ref = DOT ? *dot : dot_dummy;
+    const float* dotw = DOT ? dot_row + 4 * (lane >> 5) : nullptr;   // this lane half's rows 8q + 4h + i of the 32-float row
     constexpr int R = PD + 1;
     constexpr int NQ = NKH + NKD;            // k-steps after the optional pre segment
     constexpr int QSYNC = NQ - PD;           // the barrier sits in front of this k-step
@@ -537,14 +576,14 @@ __device__ __forceinline__ void tile_mma(WalkerT& wk, Frags& F, int lane, bool u
 #else
 #define NWE_EPI_ON true
 #endif
-        if constexpr (NWE_EPI_ON && PEND && Plan::STAGED) epi_gap<Plan, X3, GPK * q>(prev, E, inv_scale, lower, y0h, y0l, y1h, y1l);
+        if constexpr (NWE_EPI_ON && PEND && Plan::STAGED) epi_gap<Plan, X3, GPK * q, DOT>(prev, E, inv_scale, lower, y0h, y0l, y1h, y1l, dotw, dot_ref);
         if (NWE_EPI_ON && PEND && !Plan::STAGED && q < NKH) {
             // short tiles whose outputs feed their own last k-steps have no room for the staged plan: element e runs in
             // k-step floor(e*(NKH-1)/16), so all sixteen are done one k-step before the tile's last
 #pragma unroll
             for (int e = 0; e < 16; ++e)
                 if ((e * (NKH - 1)) / 16 == q) {
-                    finish_elem<X3>(prev, e, inv_scale, lower, ekeep, y0h, y0l, y1h, y1l);
+                    finish_elem<X3, DOT>(prev, e, inv_scale, lower, ekeep, y0h, y0l, y1h, y1l, dotw, &dot_ref);
                     if (e == 7) asm volatile("" : "+a"(y0h), "+a"(y0l));
                 }
         }
@@ -558,11 +597,11 @@ __device__ __forceinline__ void tile_mma(WalkerT& wk, Frags& F, int lane, bool u
             __builtin_amdgcn_sched_barrier(0);
             cur.a = __builtin_amdgcn_mfma_f32_32x32x16_f16(F.lo[use], *Xh, cur.a, 0, 0, 0);
             dma();
-            if constexpr (NWE_EPI_ON && PEND && Plan::STAGED) epi_gap<Plan, X3, GPK * q + 1>(prev, E, inv_scale, lower, y0h, y0l, y1h, y1l);
+            if constexpr (NWE_EPI_ON && PEND && Plan::STAGED) epi_gap<Plan, X3, GPK * q + 1, DOT>(prev, E, inv_scale, lower, y0h, y0l, y1h, y1l, dotw, dot_ref);
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
             __builtin_amdgcn_sched_barrier(0);
             cur.a = __builtin_amdgcn_mfma_f32_32x32x16_f16(F.hi[use], *Xl, cur.a, 0, 0, 0);
-            if constexpr (NWE_EPI_ON && PEND && Plan::STAGED) epi_gap<Plan, X3, GPK * q + 2>(prev, E, inv_scale, lower, y0h, y0l, y1h, y1l);
+            if constexpr (NWE_EPI_ON && PEND && Plan::STAGED) epi_gap<Plan, X3, GPK * q + 2, DOT>(prev, E, inv_scale, lower, y0h, y0l, y1h, y1l, dotw, dot_ref);
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -586,12 +625,14 @@ __device__ __forceinline__ void tile_mma(WalkerT& wk, Frags& F, int lane, bool u
 // this layer's last tile, still pending.  Chunk sizes for the DMA schedule, in pieces per wave: this layer's chunks
 // N_THIS (+2 when use_g), the following layer's N_AFTER (+2 when extra_after), and `first_nb` = what tile 0 still
 // has to issue of chunk T+1 (0 at the very start of a pass, where chunks 0 and 1 are streamed up front).
-template <int NT, int NKP, int NKH, bool X3, bool PEND0, int N_AFTER, bool PASS_START, class WalkerT>
+template <int NT, int NKP, int NKH, bool X3, bool PEND0, int N_AFTER, bool PASS_START, bool DOT = false, class WalkerT>
 __device__ __forceinline__ void layer(WalkerT& wk, Frags& F, int lane, bool use_g, bool extra_after, const h8* Ghi, const h8* Glo,
                                       h8* Xhi, h8* Xlo, h8* Yhi, h8* Ylo, Pend& P0, Pend& P1, float inv_scale, float lower_prev,
-                                      float lower, int na_last_override = -1) {
+                                      float lower, int na_last_override = -1, const float* dot_tab = nullptr, float* dot = nullptr) {
     static_assert(NT % 2 == 0 && NT >= 4, "tiles per layer must be even (accumulator ping-pong)");
     constexpr int N_THIS = 2 * NKH / kWaves;
+    // DOT: this layer's activations also feed a one-row linear layer; tile rt's share is accumulated with its epilogue, i.e. in
+    // tile rt + 1 (row rt of dot_tab); the last tile's share rides on the epilogue the caller runs in the tile after the layer.
 #pragma unroll
     for (int rt = 0; rt < NT; ++rt) {
         Pend& cur = (rt & 1) ? P1 : P0;
@@ -599,6 +640,7 @@ __device__ __forceinline__ void layer(WalkerT& wk, Frags& F, int lane, bool use_
         // chunk T+1 / T+2 seen from tile rt: inside the layer both are this layer's; at its end the next layer's
         const bool ebB = rt + 1 < NT ? use_g : extra_after;
         const bool ebA = rt + 2 < NT ? use_g : extra_after;
+        const float* drow = DOT ? dot_tab + (rt - 1) * 32 : nullptr;
         if (rt == 0) {
             constexpr int NB0 = PASS_START ? 0 : N_THIS;
             if constexpr (PEND0) {
@@ -611,17 +653,17 @@ __device__ __forceinline__ void layer(WalkerT& wk, Frags& F, int lane, bool use_
                                                                        cur, prev, inv_scale, lower_prev, d0, d1, d2, d3);
             }
         } else if (rt + 2 < NT) {
-            tile_mma<NKP, NKH, 0, 0, X3, true, N_THIS, N_THIS, true>(wk, F, lane, use_g, ebB, ebA, Ghi, Glo, Xhi, Xlo, nullptr, nullptr, cur,
+            tile_mma<NKP, NKH, 0, 0, X3, true, N_THIS, N_THIS, true, false, DOT>(wk, F, lane, use_g, ebB, ebA, Ghi, Glo, Xhi, Xlo, nullptr, nullptr, cur,
                                                                      prev, inv_scale, lower, Yhi[2 * rt - 2], Ylo[2 * rt - 2], Yhi[2 * rt - 1],
-                                                                     Ylo[2 * rt - 1]);
+                                                                     Ylo[2 * rt - 1], -1, drow, dot);
         } else if (rt + 1 < NT) {
-            tile_mma<NKP, NKH, 0, 0, X3, true, N_THIS, N_AFTER, true>(wk, F, lane, use_g, ebB, ebA, Ghi, Glo, Xhi, Xlo, nullptr, nullptr, cur,
+            tile_mma<NKP, NKH, 0, 0, X3, true, N_THIS, N_AFTER, true, false, DOT>(wk, F, lane, use_g, ebB, ebA, Ghi, Glo, Xhi, Xlo, nullptr, nullptr, cur,
                                                                       prev, inv_scale, lower, Yhi[2 * rt - 2], Ylo[2 * rt - 2], Yhi[2 * rt - 1],
-                                                                      Ylo[2 * rt - 1]);
+                                                                      Ylo[2 * rt - 1], -1, drow, dot);
         } else {
-            tile_mma<NKP, NKH, 0, 0, X3, true, N_AFTER, N_AFTER, true>(wk, F, lane, use_g, ebB, ebA, Ghi, Glo, Xhi, Xlo, nullptr, nullptr, cur,
+            tile_mma<NKP, NKH, 0, 0, X3, true, N_AFTER, N_AFTER, true, false, DOT>(wk, F, lane, use_g, ebB, ebA, Ghi, Glo, Xhi, Xlo, nullptr, nullptr, cur,
                                                                        prev, inv_scale, lower, Yhi[2 * rt - 2], Ylo[2 * rt - 2], Yhi[2 * rt - 1],
-                                                                       Ylo[2 * rt - 1], na_last_override);
+                                                                       Ylo[2 * rt - 1], na_last_override, drow, dot);
         }
     }
 }
@@ -660,28 +702,38 @@ __device__ __forceinline__ void encode(float vx, float vy, float vz, int h, h8* 
     }
 }
 
-// View-layer tiles RT..NTV-1 (compile-time recursion: the DMA schedule and the ring phase depend on RT).  Tile RT
-// accumulates in P[(RT+1)&1]; tile 0 follows the alpha tile, which has no activation output to finish.  Each tile has
+// View-layer tiles RT..NTV-1 (compile-time recursion: the DMA schedule and the ring phase depend on RT).  Each tile has
 // KH + KD k-steps, which shifts the fragment ring by (KH+KD) mod (PD+1) per tile.
-template <int RT, int W, int D, bool X3, class WalkerT>
-__device__ __forceinline__ void view_tiles(WalkerT& wk, Frags& F, int lane, const h8* Ahi, const h8* Alo, const h8* GDhi,
-                                           const h8* GDlo, h8* Bhi, h8* Blo, Pend& P0, Pend& P1, float inv_scale) {
+// SIGMA_TILE (the unfolded formulation): tile 0 follows the alpha tile, which has no activation output to finish; tile RT
+// accumulates in P[(RT+1)&1].  !SIGMA_TILE (FOLD): tile 0 follows the last trunk tile directly (pending in P1) and runs its
+// epilogue - ReLU into the last two k-steps of X itself, and the last share of the alpha dot product (row NT-1 of dot_tab) -
+// so tile RT accumulates in P[RT&1].
+template <int RT, int W, int D, bool X3, bool SIGMA_TILE, class WalkerT>
+__device__ __forceinline__ void view_tiles(WalkerT& wk, Frags& F, int lane, h8* Ahi, h8* Alo, const h8* GDhi,
+                                           const h8* GDlo, h8* Bhi, h8* Blo, Pend& P0, Pend& P1, float inv_scale,
+                                           const float* dot_tab = nullptr, float* dot = nullptr) {
     using S = Shape<W, D>;
-    Pend& cur = (RT & 1) ? P0 : P1;
-    Pend& prev = (RT & 1) ? P1 : P0;
+    constexpr int par = SIGMA_TILE ? (RT + 1) & 1 : RT & 1;
+    Pend& cur = par ? P1 : P0;
+    Pend& prev = par ? P0 : P1;
     constexpr int PH = (RT * (S::KH + S::KD)) % (PD + 1);
     constexpr int NB = RT + 1 < S::NTV ? S::N_V : S::N_RGB;                            // chunk T+1
     constexpr int NA = RT + 2 < S::NTV ? S::N_V : (RT + 2 == S::NTV ? S::N_RGB : 0);   // chunk T+2
-    if constexpr (RT == 0) {
+    if constexpr (RT == 0 && SIGMA_TILE) {
         h8 d0, d1, d2, d3;
         tile_mma<0, S::KH, S::KD, PH, X3, false, NB, NA, true>(wk, F, lane, false, false, false, nullptr, nullptr, Ahi, Alo, GDhi, GDlo, cur,
                                                                prev, inv_scale, 0.f, d0, d1, d2, d3);
+    } else if constexpr (RT == 0) {
+        constexpr int L = 2 * S::NT - 2;
+        tile_mma<0, S::KH, S::KD, PH, X3, true, NB, NA, true, true, true>(wk, F, lane, false, false, false, nullptr, nullptr, Ahi, Alo, GDhi, GDlo,
+                                                                          cur, prev, inv_scale, 0.f, Ahi[L], Alo[L], Ahi[L + 1], Alo[L + 1], -1,
+                                                                          dot_tab + (S::NT - 1) * 32, dot);
     } else {
         tile_mma<0, S::KH, S::KD, PH, X3, true, NB, NA, true>(wk, F, lane, false, false, false, nullptr, nullptr, Ahi, Alo, GDhi, GDlo, cur,
                                                               prev, inv_scale, 0.f, Bhi[2 * RT - 2], Blo[2 * RT - 2], Bhi[2 * RT - 1],
                                                               Blo[2 * RT - 1]);
     }
-    if constexpr (RT + 1 < S::NTV) view_tiles<RT + 1, W, D, X3>(wk, F, lane, Ahi, Alo, GDhi, GDlo, Bhi, Blo, P0, P1, inv_scale);
+    if constexpr (RT + 1 < S::NTV) view_tiles<RT + 1, W, D, X3, SIGMA_TILE>(wk, F, lane, Ahi, Alo, GDhi, GDlo, Bhi, Blo, P0, P1, inv_scale);
 }
 
 // One MLP evaluation for the wave's 32 points.  nerf/models/nerf_model.py:45-83.
@@ -696,7 +748,7 @@ __device__ __forceinline__ void view_tiles(WalkerT& wk, Frags& F, int lane, cons
 // On entry chunks 0 and 1 of the stream are visible / in flight and F holds the first PD k-steps of chunk 0.
 template <int W, int D, int SKIP, bool X3, bool FOLD, class WalkerT>
 __device__ __forceinline__ void mlp_eval(WalkerT& wk, Frags& F, int lane, float inv_scale, h8* Ghi, h8* Glo, const char* gd_lds,
-                                         float& o_r, float& o_g, float& o_b, float& o_s) {
+                                         const float* dot_tab, float& o_r, float& o_g, float& o_b, float& o_s) {
     using S = Shape<W, D>;
     static_assert(D % 2 == 0, "trunk depth must be even");
     static_assert(SKIP < 0 || SKIP % 2 == 0, "skip layer index must be even");
@@ -723,12 +775,15 @@ __device__ __forceinline__ void mlp_eval(WalkerT& wk, Frags& F, int lane, float 
                                                         Ahi, Alo, P0, P1, inv_scale, 0.f, (!FOLD && last) ? -INFINITY : 0.f,
                                                         (!FOLD && last) ? S::N_V : -1);
     }
+    float sig = 0.f;   // FOLD: this lane half's share of _alpha_linear . h
     if constexpr (FOLD) {
-        // FOLD: the last trunk layer stands alone (A -> B); behind it come the alpha tile (a chunk of N_H pieces like a trunk
-        // layer's) and the view layer, whose chunk size the last tile needs for the head of chunk T+2.
+        // FOLD: the last trunk layer stands alone (A -> B); behind it comes the view layer at once (its chunks are N_V pieces).
+        // _alpha_linear (nerf_model.py:63) is one output row on this layer's activations h: sigma = w . h + b is accumulated
+        // in fp32 on the vector ALU with the tiles' epilogues (row rt of dot_tab holds w[32 rt .. 32 rt + 31]) instead of a
+        // 32-row MFMA tile of which one row would be used (48 of 3168 MFMAs, 16 KB of the weight stream per evaluation).
         constexpr bool G_LAST = SKIP_PAIR == NPAIR - 1;
-        layer<S::NT, G_LAST ? S::KG : 0, S::KH, X3, true, S::N_H, false>(wk, F, lane, G_LAST, false, Ghi, Glo, Ahi, Alo, Bhi, Blo, P0, P1,
-                                                                         inv_scale, 0.f, 0.f, S::N_V);
+        layer<S::NT, G_LAST ? S::KG : 0, S::KH, X3, true, S::N_V, false, true>(wk, F, lane, G_LAST, false, Ghi, Glo, Ahi, Alo, Bhi, Blo, P0, P1,
+                                                                               inv_scale, 0.f, 0.f, -1, dot_tab, &sig);
     }
     constexpr int L = 2 * S::NT - 2;
     constexpr int LV = 2 * S::NTV - 2;
@@ -743,18 +798,22 @@ __device__ __forceinline__ void mlp_eval(WalkerT& wk, Frags& F, int lane, float 
         if (X3) GDlo[k] = *reinterpret_cast<const h8*>(gd_lds + (2 * k + 1) * kTileBytes);
     }
     if constexpr (FOLD) {
-        // _alpha_linear on B = h (nerf_model.py:63); its first k-steps overlap the epilogue of the last trunk tile (P1),
-        // whose outputs are the last two k-steps of B itself (ReLU).  Rows 0 and 4 of the alpha tile hold the output row.
-        tile_mma<0, S::KH, 0, 0, X3, true, S::N_V, S::N_V, true, true>(wk, F, lane, false, false, false, nullptr, nullptr, Bhi, Blo, nullptr,
-                                                                       nullptr, P0, P1, inv_scale, 0.f, Bhi[L], Blo[L], Bhi[L + 1], Blo[L + 1]);
-        const float sigma = pend_value(P0, 0, inv_scale);
-        // folded view layer: [h (B), gamma(d)] -> A[0..KV), ReLU (nerf_model.py:64-70 with W_v[:, :W] . W_f multiplied out)
-        view_tiles<0, W, D, X3>(wk, F, lane, Bhi, Blo, GDhi, GDlo, Ahi, Alo, P0, P1, inv_scale);
-        // rgb head (nerf_model.py:74) in P1 while the last view tile (P0, NTV even) is finished into A; rows 0..2 and
-        // their copies 4..6 for the upper lane half.  Nothing is streamed behind it: the caller starts the next pass.
-        tile_mma<0, S::KV, 0, 0, X3, true, 0, 0, false, true>(wk, F, lane, false, false, false, nullptr, nullptr, Ahi, Alo, nullptr, nullptr, P1,
-                                                              P0, inv_scale, 0.f, Ahi[LV], Alo[LV], Ahi[LV + 1], Alo[LV + 1]);
+        // folded view layer: [h (B), gamma(d)] -> A[0..KV), ReLU (nerf_model.py:64-70 with W_v[:, :W] . W_f multiplied out).
+        // Its first tile runs the epilogue of the last trunk tile (P1, NT even): ReLU into the last two k-steps of B itself and
+        // the last share of the alpha dot product.  Tile RT accumulates in P[RT & 1], so the last one (NTV even) is in P1.
+        view_tiles<0, W, D, X3, false>(wk, F, lane, Bhi, Blo, GDhi, GDlo, Ahi, Alo, P0, P1, inv_scale, dot_tab, &sig);
+        // both lane halves hold half of the features: the other half's share comes over the 32-lane swap; the row behind the
+        // weights holds the bias in element 0
+        const float sigma = __fadd_rn(__fadd_rn(sig, __shfl_xor(sig, 32, 64)), dot_tab[S::NT * 32]);
+        // rgb head (nerf_model.py:74) in P0 while the last view tile (P1) is finished into A; rows 0..2 and their copies 4..6
+        // for the upper lane half.  Nothing is streamed behind it: the caller starts the next pass.
+        tile_mma<0, S::KV, 0, 0, X3, true, 0, 0, false, true>(wk, F, lane, false, false, false, nullptr, nullptr, Ahi, Alo, nullptr, nullptr, P0,
+                                                              P1, inv_scale, 0.f, Ahi[LV], Alo[LV], Ahi[LV + 1], Alo[LV + 1]);
         o_s = sigma;
+        o_r = pend_value(P0, 0, inv_scale);
+        o_g = pend_value(P0, 1, inv_scale);
+        o_b = pend_value(P0, 2, inv_scale);
+        return;
     } else {
         // _alpha_linear on B, the input of _feature_linear (nerf_model.py:63); meanwhile the last feature tile (P1) is
         // finished into A without ReLU.  Rows 0 and 4 of the alpha tile both hold the single output row.
@@ -762,7 +821,7 @@ __device__ __forceinline__ void mlp_eval(WalkerT& wk, Frags& F, int lane, float 
                                                                  P0, P1, inv_scale, -INFINITY, Ahi[L], Alo[L], Ahi[L + 1], Alo[L + 1]);
         const float sigma = pend_value(P0, 0, inv_scale);
         // view layer: [feature (A), gamma(d)] -> B[0..KV), ReLU (nerf_model.py:66-70)
-        view_tiles<0, W, D, X3>(wk, F, lane, Ahi, Alo, GDhi, GDlo, Bhi, Blo, P0, P1, inv_scale);
+        view_tiles<0, W, D, X3, true>(wk, F, lane, Ahi, Alo, GDhi, GDlo, Bhi, Blo, P0, P1, inv_scale);
         tile_mma<0, S::KV, 0, 0, X3, true, 0, 0, false, true>(wk, F, lane, false, false, false, nullptr, nullptr, Bhi, Blo, nullptr, nullptr, P1,
                                                               P0, inv_scale, 0.f, Bhi[LV], Blo[LV], Bhi[LV + 1], Blo[LV + 1]);
         o_s = sigma;
@@ -839,7 +898,9 @@ __global__ void __launch_bounds__(256) render_mfma_kernel(RenderArgs a_in, NetMf
     for (int i = threadIdx.x; i < ni; i += 256) s_u[i] = a.u_vals[i];
     float* s_bias = reinterpret_cast<float*>(smem + SM::BOFF);
     constexpr int NCH = FOLD ? S::N_CHUNKS_FOLDED : S::N_CHUNKS;   // the launcher checks n_chunks of both networks against it
-    for (int i = threadIdx.x; i < NCH * 32; i += 256) {
+    constexpr int NROWS = NCH + (FOLD ? S::N_DOT_ROWS : 0);        // FOLD: the alpha layer's weights and bias ride behind the bias rows
+    static_assert(NROWS * 32 * 4 <= SM::BIAS_BYTES, "bias table too small for the dot rows");
+    for (int i = threadIdx.x; i < NROWS * 32; i += 256) {
         s_bias[i] = nc.bias[i];
         if (ni > 0) s_bias[SM::BIAS_BYTES / 4 + i] = nf.bias[i];
     }
@@ -901,6 +962,7 @@ __global__ void __launch_bounds__(256) render_mfma_kernel(RenderArgs a_in, NetMf
     for (int pass = 0; pass < (ni > 0 ? 2 : 1); ++pass) {
         const NetMfma& net = pass == 0 ? nc : nf;
         const float* bias = s_bias + (pass == 0 ? 0 : SM::BIAS_BYTES / 4);
+        const float* dot_tab = bias + NCH * 32;
         const int Stot = pass == 0 ? ns : ns + ni;
         const float* noise = pass == 0 ? a.noise_c : a.noise_f;
         const float* raw_in = pass == 0 ? a.raw_in_c : a.raw_in_f;   // test hook: network outputs from the caller (uniform)
@@ -1005,7 +1067,7 @@ __global__ void __launch_bounds__(256) render_mfma_kernel(RenderArgs a_in, NetMf
                 wk.st_t0 = t2;
                 st_sync += t2 - t1;
 #endif
-                mlp_eval<W, D, SKIP, X3, FOLD>(wk, F, lane, net.inv_scale, Ghi, Glo, gd_lds, rr, rg, rb, rs);
+                mlp_eval<W, D, SKIP, X3, FOLD>(wk, F, lane, net.inv_scale, Ghi, Glo, gd_lds, dot_tab, rr, rg, rb, rs);
 #ifdef NWE_STAMPS
                 st_mlp += __builtin_amdgcn_s_memtime() - t2;
 #endif
@@ -1094,7 +1156,7 @@ __global__ void __launch_bounds__(256) render_mfma_kernel(RenderArgs a_in, NetMf
                 wk.st_t0 = t2;
                 st_sync += t2 - t1;
     #endif
-                mlp_eval<W, D, SKIP, X3, FOLD>(wk, F, lane, net.inv_scale, Ghi, Glo, gd_lds, rr, rg, rb, rs);
+                mlp_eval<W, D, SKIP, X3, FOLD>(wk, F, lane, net.inv_scale, Ghi, Glo, gd_lds, dot_tab, rr, rg, rb, rs);
     #ifdef NWE_STAMPS
                 st_mlp += __builtin_amdgcn_s_memtime() - t2;
     #endif

@@ -33,8 +33,8 @@ int main(void) {
     }
     CHECK(nwe_set_network(ctx, NWE_NET_COARSE, D, W, IN_XYZ, IN_DIR, -1, (const float *const *)w, (const float *const *)b) == NWE_OK);
     CHECK(nwe_flops_per_eval(ctx, NWE_NET_COARSE) == 167680);                       /* BASELINE.md section 2 */
-    CHECK(nwe_packed_bytes(ctx, NWE_NET_COARSE) == 288 * 1024);                     /* 4x128, feature layer folded */
-    CHECK(nwe_packed_bias_count(ctx, NWE_NET_COARSE) == 20 * 32);
+    CHECK(nwe_packed_bytes(ctx, NWE_NET_COARSE) == 272 * 1024);                     /* 4x128, feature layer folded, no alpha tile */
+    CHECK(nwe_packed_bias_count(ctx, NWE_NET_COARSE) == (19 + 5) * 32);             /* 19 chunks + the alpha layer's 4 + 1 dot rows */
     const float scale = nwe_packed_scale(ctx, NWE_NET_COARSE);
     CHECK(scale > 0.f && fabsf(log2f(scale) - roundf(log2f(scale))) == 0.f);        /* a power of two */
     CHECK(nwe_debug_set_fold(ctx, 0) == NWE_OK);

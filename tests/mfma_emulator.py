@@ -104,19 +104,43 @@ def mlp_eval(stream_bytes, bias_tab, scale, pts, dirs, D, W, skip, three_pass=Tr
     A = layer(st, NT, [G], 0.0, three_pass)
     npair = D // 2
     skip_pair = -1 if skip < 0 else skip // 2
+    h_tiles = []                                           # folded: the fp32 activations of the last trunk layer, tile by tile
     for pair in range(npair):
         last = pair == npair - 1
         segs = ([G] if pair == skip_pair else []) + [A]
-        B = layer(st, NT, segs, 0.0, three_pass)
         if folded and last:
+            his, los = [], []
+            for _ in range(NT):
+                t = mma_tile(st, segs, three_pass)
+                h_tiles.append(np.maximum(t, np.float32(0.0)))
+                hi, lo = tile_to_operand(t, 0.0)
+                his.append(hi); los.append(lo)
+            B = (np.concatenate(his, 0), np.concatenate(los, 0))
             break
+        B = layer(st, NT, segs, 0.0, three_pass)
         A = layer(st, NT, [B], -np.inf if last else 0.0, three_pass)
-    t = mma_tile(st, [B], three_pass)                      # _alpha_linear reads h = B in both formulations
-    assert np.array_equal(t[0], t[4]), "alpha tile rows 0 and 4 must be copies"
-    sigma = t[0]
+    if folded:
+        # _alpha_linear is not a tile of the folded stream: sigma = w . h + b in fp32 on the vector ALU, accumulated with the
+        # epilogues of the last trunk layer's tiles.  Its weights are the NT rows behind the chunks' bias rows (row rt element i
+        # = weight of feature 32 rt + i), its bias element 0 of the row after them.  Each lane half sums its own rows
+        # (8g + 4h + i of every tile, in tile / group / element order), the halves are added, then the bias.
+        n_chunks = len(bias_tab) - (NT + 1)
+        dot = bias_tab[n_chunks:]
+        part = np.zeros((2, pts.shape[0]), dtype=np.float32)
+        for rt in range(NT):
+            for e in range(16):
+                for hh in range(2):
+                    row = 8 * (e >> 2) + 4 * hh + (e & 3)
+                    part[hh] = (dot[rt, row].astype(np.float64) * h_tiles[rt][row].astype(np.float64) + part[hh].astype(np.float64)).astype(np.float32)   # fmaf
+        sigma = ((part[0] + part[1]).astype(np.float32) + dot[NT, 0]).astype(np.float32)
+    else:
+        t = mma_tile(st, [B], three_pass)                  # _alpha_linear reads h = B, the input of _feature_linear
+        assert np.array_equal(t[0], t[4]), "alpha tile rows 0 and 4 must be copies"
+        sigma = t[0]
+        n_chunks = len(bias_tab)
     Bv = layer(st, W // 64, [B if folded else A, GD], 0.0, three_pass)
     t = mma_tile(st, [Bv], three_pass)
     assert np.array_equal(t[0:3], t[4:7]), "rgb tile rows 4..6 must copy rows 0..2"
     assert st.pos == len(stream_bytes), (st.pos, len(stream_bytes))
-    assert st.chunk == len(bias_tab), (st.chunk, len(bias_tab))
+    assert st.chunk == n_chunks, (st.chunk, n_chunks)
     return np.stack([t[0], t[1], t[2], sigma], axis=1)

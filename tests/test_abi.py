@@ -84,8 +84,14 @@ def test_stream_layout_properties():
     assert np.abs(hi).max() < 2.0 ** 15                                        # scaled into fp16 range with headroom
     nz = lo[lo != 0]
     assert (np.abs(nz) >= 2.0 ** -14).mean() > 0.99                            # lo halves are fp16-normal
-    # head tiles: rows 4..7 repeat rows 0..3 so that both lane halves see the outputs
-    assert np.array_equal(bias[-1][:3], sd["_rgb_linear.bias"]) and np.array_equal(bias[-1][4:7], sd["_rgb_linear.bias"])
+    # folded stream: behind the chunks' bias rows come the dot rows of _alpha_linear (W/32 rows of weights in the row order of
+    # the last trunk layer's tiles, then its bias); the last chunk is the rgb head tile, whose rows 4..7 repeat rows 0..3 so
+    # that both lane halves see the outputs
+    n_dot = 128 // 32 + 1
+    assert np.array_equal(bias[-n_dot:-1].reshape(-1), sd["_alpha_linear.weight"][0]) and bias[-1][0] == sd["_alpha_linear.bias"][0]
+    assert not bias[-1][1:].any()
+    rgb_row = bias[-n_dot - 1]
+    assert np.array_equal(rgb_row[:3], sd["_rgb_linear.bias"]) and np.array_equal(rgb_row[4:7], sd["_rgb_linear.bias"])
 
 
 def test_kernel_owns_m0():
