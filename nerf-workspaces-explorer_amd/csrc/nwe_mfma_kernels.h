@@ -364,8 +364,24 @@ struct Walker {
         // M0 is written by the first piece of a group and by the piece the tail would start with (6 of an 8-piece quarter, 7
         // of a 9-piece one; the first tail piece of a 10-piece quarter, 8, opens a group anyway, and so does 8 of 9).
         const bool set_m0 = (i & 3) == 0 || (X3 && i == tail_piece);
-#define NWE_GLDS(OFF) asm volatile("global_load_lds_dwordx4 %0, %1 offset:" #OFF :: "v"(lane_off), "s"(src) : "memory")
-#define NWE_GLDS_M0(OFF) asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:" #OFF \
+// Cache policy of the weight stream (NWE_GLDS_POLICY, timing experiments): 0 default, 1 sc1 (bypass the CU's vector L1, which
+// never sees a piece twice), 2 nt, 3 sc0 sc1, 4 sc1 nt.
+#ifndef NWE_GLDS_POLICY
+#define NWE_GLDS_POLICY 0
+#endif
+#if NWE_GLDS_POLICY == 1
+#define NWE_GLDS_POL " sc1"
+#elif NWE_GLDS_POLICY == 2
+#define NWE_GLDS_POL " nt"
+#elif NWE_GLDS_POLICY == 3
+#define NWE_GLDS_POL " sc0 sc1"
+#elif NWE_GLDS_POLICY == 4
+#define NWE_GLDS_POL " sc1 nt"
+#else
+#define NWE_GLDS_POL ""
+#endif
+#define NWE_GLDS(OFF) asm volatile("global_load_lds_dwordx4 %0, %1 offset:" #OFF NWE_GLDS_POL :: "v"(lane_off), "s"(src) : "memory")
+#define NWE_GLDS_M0(OFF) asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:" #OFF NWE_GLDS_POL \
                                       :: "v"(lane_off), "s"(src), "s"(dst) : "memory")
         if (set_m0) {   // point M0 at the group's LDS destination (one wait state before the DMA)
             switch (i & 3) {
