@@ -152,3 +152,11 @@ def test_host_code_under_sanitizers():
     out = subprocess.run(["make", "-C", csrc, "asan"], capture_output=True, text=True, timeout=900)
     assert out.returncode == 0 and "abi_smoke ok" in out.stdout, (out.stdout[-1500:], out.stderr[-3000:])
     assert "AddressSanitizer" not in out.stderr and "runtime error" not in out.stderr
+
+
+def test_graft_entry_build_runs():
+    """The driver's "does it build" step, end to end: `make` (a no-op when the library is current), the M0 check, the oracle
+    import and the packed-stream sanity check of __graft_entry__.build() - a stale constant there fails HERE, not at round end."""
+    import subprocess
+    out = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.build()"], cwd=ROOT, capture_output=True, text=True, timeout=1800)
+    assert out.returncode == 0 and "build ok" in out.stdout, (out.stdout[-1500:], out.stderr[-1500:])
