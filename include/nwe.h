@@ -77,6 +77,9 @@ typedef struct nwe_outputs {
                                    rounding difference in the coarse weights IN THE REFERENCE ALGORITHM ITSELF */
     float *sample_switch;/* [R]    smallest |denom - 1e-5| before the replacement: the distance of the ray's samples
                                    from the discontinuity of :114 */
+    float *feat_map;     /* [R,W/2] feat_map_fine (experiment.endpoint_feat, handler.py:248-254,270-271): the view layer's outputs
+                                   of the FINE pass composited like rgb (model_utils.py:87-89; the reference takes the last 128
+                                   channels, i.e. W = 256).  NWE_PREC_F32 only, networks with view directions, n_importance > 0 */
     uint32_t *flags;     /* [1]    NWE_FLAG_* bits, OR-ed (caller zeroes it) */
 } nwe_outputs;
 
@@ -100,6 +103,15 @@ const char *nwe_last_error(const nwe_ctx *ctx);
  *                  _feature_linear, _alpha_linear, _rgb_linear */
 int nwe_set_network(nwe_ctx *ctx, int which, int depth, int width, int in_xyz, int in_dir, int skip_layer,
                     const float *const *w, const float *const *b);
+
+/* The same for NeRFModel(use_view_dirs=False) (nerf/models/nerf_model.py:41-43,82-83; the handler builds it with
+ * input_ch_views = 0 and output_ch = 5, handler.py:97-119): the trunk and ONE output layer.  w, b: depth+1 pointers each,
+ * _pts_linears[0..depth-1] then _output_linear [output_ch, width]; output_ch >= 4, channels 0..2 are rgb_raw and channel 3
+ * sigma_raw (model_utils.py:62,71), further channels are ignored as the reference ignores them.  Such networks render with
+ * NWE_PREC_F32 only (no MFMA instantiation), take 8-column rays in nwe_render_rays ([o d near far], nerf/rays/rays.py:26-30
+ * without the view directions) and both networks of a context must be of the same kind. */
+int nwe_set_network_no_view_dirs(nwe_ctx *ctx, int which, int depth, int width, int in_xyz, int skip_layer, int output_ch,
+                                 const float *const *w, const float *const *b);
 
 /* Sampling tables computed by the host with torch.linspace (its bits are not i/(n-1)):
  *   t_vals[n_samples] = linspace(0,1,Ns) and one_minus_t[n_samples] = 1 - t_vals  (handler.py:216-218)
@@ -147,7 +159,8 @@ int nwe_debug_peer_access(const nwe_ctx *first, const nwe_ctx *tile);
 int nwe_create_rays(nwe_ctx *ctx, const float *c2w, int n_poses, int H, int W, float fx, float fy, float cx, float cy,
                     float near, float far, int row_begin, int row_end, float *rays_out_dev, void *stream);
 
-/* Render precomputed rays: DEVICE [n_rays,11] fp32 = [o(3) d(3) near far viewdir(3)] (rays.py:26-30).
+/* Render precomputed rays: DEVICE [n_rays,11] fp32 = [o(3) d(3) near far viewdir(3)] (rays.py:26-30); [n_rays,8] without the
+ * view directions when the context's networks were set with nwe_set_network_no_view_dirs.
  * Replaces: NeRFReplicaInferenceHandler._render_rays(flat_rays) (handler.py:187-201). */
 int nwe_render_rays(nwe_ctx *ctx, const float *rays_dev, int64_t n_rays, int precision, const nwe_outputs *out,
                     void *stream);

@@ -14,14 +14,14 @@ PREC_F16X3, PREC_F16X1, PREC_F32 = 0, 1, 2
 PRECISIONS = {"f16x3": PREC_F16X3, "f16x1": PREC_F16X1, "f32": PREC_F32}
 
 OUTPUT_FIELDS = ("rgb", "depth", "acc", "disp", "z_std", "rgb_coarse", "depth_coarse", "acc_coarse", "disp_coarse",
-                 "raw_coarse", "raw_fine", "z_fine", "weights_coarse", "sample_cond", "sample_amp", "sample_switch", "flags")
+                 "raw_coarse", "raw_fine", "z_fine", "weights_coarse", "sample_cond", "sample_amp", "sample_switch", "feat_map", "flags")
 
 # every symbol include/nwe.h declares (tests/test_abi.py checks the library exports all of them)
 SYMBOLS = ("nwe_create", "nwe_destroy", "nwe_last_error", "nwe_set_network", "nwe_set_sampling", "nwe_render", "nwe_render_tiled",
            "nwe_create_rays", "nwe_render_rays", "nwe_to8b", "nwe_flops_per_eval", "nwe_last_kernel_ms", "nwe_packed_bytes",
            "nwe_packed_copy", "nwe_packed_bias_count", "nwe_packed_bias_copy", "nwe_packed_scale",
            "nwe_debug_set_fine_depths", "nwe_debug_set_raw", "nwe_debug_set_coarse_weights", "nwe_debug_set_fold", "nwe_set_train_tables", "nwe_set_white_background", "nwe_debug_set_decomposition", "nwe_debug_last_plan", "nwe_debug_set_stamps", "nwe_selftest",
-           "nwe_last_warning", "nwe_debug_peer_access")
+           "nwe_last_warning", "nwe_debug_peer_access", "nwe_set_network_no_view_dirs")
 
 
 class Outputs(C.Structure):
@@ -52,6 +52,7 @@ def load() -> C.CDLL:
         "nwe_destroy": (None, [P]),
         "nwe_last_error": (C.c_char_p, [P]),
         "nwe_set_network": (I, [P, I, I, I, I, I, I, C.POINTER(P), C.POINTER(P)]),
+        "nwe_set_network_no_view_dirs": (I, [P, I, I, I, I, I, I, C.POINTER(P), C.POINTER(P)]),
         "nwe_set_sampling": (I, [P, P, P, I, P, I]),
         "nwe_render": (I, [P, P, I, I, I, F, F, F, F, F, F, I, I, I, C.POINTER(Outputs), P]),
         "nwe_render_tiled": (I, [C.POINTER(P), I, P, I, I, I, F, F, F, F, F, F, I, P, P, P, P, P]),

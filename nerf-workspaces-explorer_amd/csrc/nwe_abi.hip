@@ -15,6 +15,7 @@ namespace {
 struct NetState {
     bool set = false;
     int D = 0, W = 0, in_xyz = 0, in_dir = 0, skip = -1;
+    int out_ch = 0;                // use_view_dirs=False (in_dir == 0): rows of _output_linear
     int64_t flops = 0;
     std::vector<float> blob;       // fp32 kernel: per layer Wt[k][n] then bias
     NetF32 f32 = {};
@@ -256,8 +257,13 @@ void pack_f32(NetState& n, const float* const* w, const float* const* b) {
     const int D = n.D, W = n.W;
     n.f32 = {};
     n.f32.D = D; n.f32.W = W; n.f32.in_xyz = n.in_xyz; n.f32.in_dir = n.in_dir; n.f32.skip = n.skip;
+    n.f32.out_ch = n.out_ch;
     n.f32.pts[0] = add(0, n.in_xyz, W);
     for (int i = 1; i < D; ++i) n.f32.pts[i] = add(i, i == n.skip + 1 ? W + n.in_xyz : W, W);
+    if (n.in_dir == 0) {                    // nerf_model.py:82-83: outputs = _output_linear(h)
+        n.f32.output = add(D, W, n.out_ch);
+        return;
+    }
     n.f32.views = add(D, W + n.in_dir, W / 2);
     n.f32.feature = add(D + 1, W, W);
     n.f32.alpha = add(D + 2, W, 1);
@@ -267,6 +273,7 @@ void pack_f32(NetState& n, const float* const* w, const float* const* b) {
 int64_t algo_flops(const NetState& n) {   // 2 x MACs of nerf_model.py:53-76
     int64_t mac = (int64_t)n.in_xyz * n.W;
     for (int i = 1; i < n.D; ++i) mac += (int64_t)(i == n.skip + 1 ? n.W + n.in_xyz : n.W) * n.W;
+    if (n.in_dir == 0) return 2 * (mac + (int64_t)n.W * n.out_ch);
     mac += n.W /*alpha*/ + (int64_t)n.W * n.W /*feature*/ + (int64_t)(n.W + n.in_dir) * (n.W / 2) + (int64_t)(n.W / 2) * 3;
     return 2 * mac;
 }
@@ -332,6 +339,14 @@ int check_ready(nwe_ctx* ctx, const nwe_outputs* out, int precision) {
     if (ctx->ni > 0 && !ctx->net[1].set) return fail(ctx, NWE_ERR_STATE, "fine network not set but n_importance > 0");
     if (precision != NWE_PREC_F16X3 && precision != NWE_PREC_F16X1 && precision != NWE_PREC_F32)
         return fail(ctx, NWE_ERR_INVALID, "unknown precision");
+    if (ctx->ni > 0 && (ctx->net[0].in_dir == 0) != (ctx->net[1].in_dir == 0))
+        return fail(ctx, NWE_ERR_STATE, "coarse and fine networks must both have, or both lack, view directions");
+    if (out->feat_map) {
+        if (ctx->ni <= 0 || ctx->net[1].in_dir == 0)
+            return fail(ctx, NWE_ERR_INVALID, "feat_map is the fine pass's view-layer output: it needs n_importance > 0 and networks with view directions");
+        if (precision != NWE_PREC_F32)
+            return fail(ctx, NWE_ERR_UNSUPPORTED, "feat_map (endpoint_feat) is computed by the NWE_PREC_F32 kernel only");
+    }
     if (precision != NWE_PREC_F32) {
         if (!ctx->net[0].mfma_ok || (ctx->ni > 0 && !ctx->net[1].mfma_ok))
             return fail(ctx, NWE_ERR_UNSUPPORTED,
@@ -410,25 +425,19 @@ void nwe_destroy(nwe_ctx* c) {
 
 const char* nwe_last_error(const nwe_ctx* c) { return c ? c->err.c_str() : g_create_error.c_str(); }
 
-int nwe_set_network(nwe_ctx* c, int which, int depth, int width, int in_xyz, int in_dir, int skip_layer,
-                    const float* const* w, const float* const* b) {
-    if (!c || !w || !b) return fail(c, NWE_ERR_INVALID, "null argument");
-    if (which != NWE_NET_COARSE && which != NWE_NET_FINE) return fail(c, NWE_ERR_INVALID, "which must be 0 or 1");
-    if (depth < 1 || depth > kMaxDepth) return fail(c, NWE_ERR_UNSUPPORTED, "depth must be in 1..16");
-    if (width < 2 || width > 256 || width % 2) return fail(c, NWE_ERR_UNSUPPORTED, "width must be even and <= 256");
-    if (in_xyz < 3 || in_xyz > 93 || (in_xyz - 3) % 6 || in_dir < 3 || in_dir > 63 || (in_dir - 3) % 6)
-        return fail(c, NWE_ERR_UNSUPPORTED, "encoded widths must be 3 + 6*num_freqs (xyz <= 93, dir <= 63)");
-    if (skip_layer < -1 || skip_layer >= depth - 1) skip_layer = -1;   // a skip after the last trunk layer never feeds a layer
-    for (int i = 0; i < depth + 4; ++i)
+static int set_network_impl(nwe_ctx* c, int which, int depth, int width, int in_xyz, int in_dir, int skip_layer, int out_ch,
+                            const float* const* w, const float* const* b) {
+    const int n_layers = in_dir == 0 ? depth + 1 : depth + 4;
+    for (int i = 0; i < n_layers; ++i)
         if (!w[i] || !b[i]) return fail(c, NWE_ERR_INVALID, "null weight or bias pointer");
     NetState& n = c->net[which];
     n.set = false;   // stays false if anything below fails
-    n.D = depth; n.W = width; n.in_xyz = in_xyz; n.in_dir = in_dir; n.skip = skip_layer;
+    n.D = depth; n.W = width; n.in_xyz = in_xyz; n.in_dir = in_dir; n.skip = skip_layer; n.out_ch = out_ch;
     n.flops = algo_flops(n);
     pack_f32(n, w, b);
     n.folded = c->fold != 0;
-    n.mfma_ok = mfma_supported(depth, width, in_xyz, in_dir, skip_layer, n.folded);
-    if (n.mfma_ok) pack_mfma(n, w, b); else { n.stream.clear(); n.bias_tab.clear(); }
+    n.mfma_ok = in_dir != 0 && mfma_supported(depth, width, in_xyz, in_dir, skip_layer, n.folded);
+    if (n.mfma_ok) pack_mfma(n, w, b); else { n.stream.clear(); n.bias_tab.clear(); n.n_chunks = 0; }
     n.mf = {};
     n.mf.D = depth; n.mf.W = width; n.mf.skip = skip_layer; n.mf.folded = n.folded ? 1 : 0;
     n.mf.n_tiles = (int)(n.stream.size() / kTileBytes);
@@ -454,6 +463,30 @@ int nwe_set_network(nwe_ctx* c, int which, int depth, int width, int in_xyz, int
     }
     n.set = true;
     return NWE_OK;
+}
+
+int nwe_set_network(nwe_ctx* c, int which, int depth, int width, int in_xyz, int in_dir, int skip_layer,
+                    const float* const* w, const float* const* b) {
+    if (!c || !w || !b) return fail(c, NWE_ERR_INVALID, "null argument");
+    if (which != NWE_NET_COARSE && which != NWE_NET_FINE) return fail(c, NWE_ERR_INVALID, "which must be 0 or 1");
+    if (depth < 1 || depth > kMaxDepth) return fail(c, NWE_ERR_UNSUPPORTED, "depth must be in 1..16");
+    if (width < 2 || width > 256 || width % 2) return fail(c, NWE_ERR_UNSUPPORTED, "width must be even and <= 256");
+    if (in_xyz < 3 || in_xyz > 93 || (in_xyz - 3) % 6 || in_dir < 3 || in_dir > 63 || (in_dir - 3) % 6)
+        return fail(c, NWE_ERR_UNSUPPORTED, "encoded widths must be 3 + 6*num_freqs (xyz <= 93, dir <= 63)");
+    if (skip_layer < -1 || skip_layer >= depth - 1) skip_layer = -1;   // a skip after the last trunk layer never feeds a layer
+    return set_network_impl(c, which, depth, width, in_xyz, in_dir, skip_layer, 0, w, b);
+}
+
+int nwe_set_network_no_view_dirs(nwe_ctx* c, int which, int depth, int width, int in_xyz, int skip_layer, int output_ch,
+                                 const float* const* w, const float* const* b) {
+    if (!c || !w || !b) return fail(c, NWE_ERR_INVALID, "null argument");
+    if (which != NWE_NET_COARSE && which != NWE_NET_FINE) return fail(c, NWE_ERR_INVALID, "which must be 0 or 1");
+    if (depth < 1 || depth > kMaxDepth) return fail(c, NWE_ERR_UNSUPPORTED, "depth must be in 1..16");
+    if (width < 2 || width > 256 || width % 2) return fail(c, NWE_ERR_UNSUPPORTED, "width must be even and <= 256");
+    if (in_xyz < 3 || in_xyz > 93 || (in_xyz - 3) % 6) return fail(c, NWE_ERR_UNSUPPORTED, "encoded width must be 3 + 6*num_freqs (<= 93)");
+    if (output_ch < 4 || output_ch > 256) return fail(c, NWE_ERR_UNSUPPORTED, "output_ch must be in 4..256 (rgb_raw, sigma_raw, ignored rest)");
+    if (skip_layer < -1 || skip_layer >= depth - 1) skip_layer = -1;
+    return set_network_impl(c, which, depth, width, in_xyz, 0, skip_layer, output_ch, w, b);
 }
 
 int nwe_set_sampling(nwe_ctx* c, const float* t_vals, const float* one_minus_t, int n_samples, const float* u,
@@ -657,6 +690,7 @@ int nwe_render_rays(nwe_ctx* c, const float* rays_dev, int64_t n_rays, int preci
     if (rc) return rc;
     RenderArgs a = {};
     a.rays = rays_dev; a.n_rays = n_rays; a.W = 1; a.rows = 1;
+    a.ray_cols = c->net[0].in_dir == 0 ? 8 : 11;                       // rays.py:22-30: no view-direction columns without view dirs
     a.z_fine_in = c->dbg_z_fine; a.raw_in_c = c->dbg_raw_c; a.raw_in_f = c->dbg_raw_f; a.w_in = c->dbg_w;
     c->dbg_z_fine = c->dbg_raw_c = c->dbg_raw_f = c->dbg_w = nullptr;
     a.t_rand = c->trn_t; a.noise_c = c->trn_nc; a.noise_f = c->trn_nf; a.u_rand = c->trn_u;

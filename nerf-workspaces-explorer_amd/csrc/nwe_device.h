@@ -22,6 +22,7 @@ constexpr int kMaxImportance = 256;  // n_importance upper bound
 struct RenderArgs {
     // ray source: either precomputed rays [n_rays,11] or pinhole poses
     const float* rays;       // device, may be null -> generate from poses
+    int ray_cols;            // columns of `rays`: 11, or 8 for networks without view directions (rays.py:22-30)
     const float* poses;      // device, n_poses x 16 (row-major c2w)
     int64_t n_rays;          // total rays of the call
     int64_t ray_first;       // first ray of THIS launch (a call may be split into launches with different decompositions)
@@ -84,11 +85,11 @@ __device__ __forceinline__ Ray make_ray(const RenderArgs& a, const RaySeed& s) {
     Ray r;
     r.vx = r.vy = r.vz = 0.f;
     if (a.rays) {  // handler.py:210-214: columns [o d near far viewdir]
-        const float* p = a.rays + (int64_t)s.pose * 11;
+        const float* p = a.rays + (int64_t)s.pose * a.ray_cols;
         r.ox = p[0]; r.oy = p[1]; r.oz = p[2];
         r.dx = p[3]; r.dy = p[4]; r.dz = p[5];
         r.near = p[6]; r.far = p[7];
-        if (VIEW) { r.vx = p[8]; r.vy = p[9]; r.vz = p[10]; }
+        if (VIEW && a.ray_cols > 8) { r.vx = p[8]; r.vy = p[9]; r.vz = p[10]; }
     } else {
         const float* m = a.poses + s.pose * 16;
         // rays.py:67: 3x3 @ 3x1 as torch's CPU bmm does it: products summed left to right, no FMA

@@ -17,6 +17,8 @@ struct NetF32 {
     int D, W, in_xyz, in_dir, skip;
     LayerF32 pts[16];
     LayerF32 views, feature, alpha, rgb;
+    LayerF32 output;     // use_view_dirs=False (in_dir == 0): _output_linear [out_ch, W] instead of the four heads
+    int out_ch;
 };
 constexpr int kMaxDepth = 16;
 

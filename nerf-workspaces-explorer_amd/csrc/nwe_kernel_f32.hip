@@ -83,6 +83,7 @@ __global__ void __launch_bounds__(256) render_f32_kernel(RenderArgs a, NetF32 nc
     __shared__ __attribute__((aligned(16))) float s_hb[256 * kRP];
     __shared__ __attribute__((aligned(16))) float s_pt[3 * kRP];
     __shared__ __attribute__((aligned(16))) float s_raw[4 * kRP];
+    __shared__ float s_wcur[kRP];   // endpoint_feat: the weight of the current sample, per ray of the packet
     __shared__ float s_w[kMaxSamples * kRP];
     __shared__ float s_t[kMaxSamples], s_omt[kMaxSamples], s_u[kMaxImportance];
 
@@ -122,6 +123,11 @@ __global__ void __launch_bounds__(256) render_f32_kernel(RenderArgs a, NetF32 nc
             if (owner) for (int s = 0; s < ns; ++s) s_w[s * kRP + tid] = a.w_in[rrow * ns + s];
             continue;
         }
+        const bool want_feat = pass == 1 && a.out.feat_map != nullptr && !raw_in;   // uniform
+        float facc[kRP];
+#pragma unroll
+        for (int p = 0; p < kRP; ++p) facc[p] = 0.f;
+        const float* s_feat = s_ha;
         float z_cur = 0.f, z_next = 0.f;
         if (owner) {
             comp.reset();
@@ -161,11 +167,20 @@ __global__ void __launch_bounds__(256) render_f32_kernel(RenderArgs a, NetF32 nc
                 else dense16(net.blob, net.pts[i], cur, net.W, nullptr, 0, nxt, true);
                 float* t = cur; cur = nxt; nxt = t;
             }
+            if (net.in_dir == 0) {
+                // use_view_dirs=False, nerf_model.py:82-83: outputs = _output_linear(h); channels 0..2 rgb_raw, 3 sigma_raw
+                // (model_utils.py:62,71), the rest unused.  out_ch rows land in nxt, the four that matter are copied.
+                dense16(net.blob, net.output, cur, net.W, nullptr, 0, nxt, false);
+                if (tid < 4 * kRP) s_raw[tid] = nxt[tid];
+                __syncthreads();
+            } else {
             // heads: nerf_model.py:63-74.  alpha (1 row) goes to s_raw row 3, feature to nxt, views to cur, rgb to s_raw rows 0..2
             dense16(net.blob, net.alpha, cur, net.W, nullptr, 0, s_raw + 3 * kRP, false);
             dense16(net.blob, net.feature, cur, net.W, nullptr, 0, nxt, false);
             dense16(net.blob, net.views, nxt, net.W, s_gd, net.in_dir, cur, true);
             dense16(net.blob, net.rgb, cur, net.W / 2, nullptr, 0, s_raw, false);
+            s_feat = cur;                         // the view layer's output [W/2][16]: the endpoint feature (nerf_model.py:72-73)
+            }
             }
             if (owner) {
                 const float rr = s_raw[0 * kRP + tid], rg = s_raw[1 * kRP + tid], rb = s_raw[2 * kRP + tid],
@@ -173,6 +188,7 @@ __global__ void __launch_bounds__(256) render_f32_kernel(RenderArgs a, NetF32 nc
                 const float* nz = pass == 0 ? a.noise_c : a.noise_f;
                 const float w = comp.step(rr, rg, rb, rs, z_cur, z_next, s + 1 == S, ray.dnorm, nz ? nz[rrow * S + s] : 0.f);
                 if (pass == 0) s_w[s * kRP + tid] = w;
+                if (want_feat) s_wcur[tid] = w;
                 if (live) {
                     if (pass == 0 && a.out.weights_coarse) a.out.weights_coarse[ridx * S + s] = w;
                     float* raw = pass == 0 ? a.out.raw_coarse : a.out.raw_fine;
@@ -185,8 +201,21 @@ __global__ void __launch_bounds__(256) render_f32_kernel(RenderArgs a, NetF32 nc
                 }
                 z_cur = z_next;
             }
+            if (want_feat) {
+                // feat_map = sum_s weights * feat (model_utils.py:87-89): thread n owns channel n for the 16 rays of the packet.
+                // s_feat is rewritten by the next sample's trunk only behind a barrier every thread passes after this.
+                __syncthreads();
+                if (tid < net.W / 2) {
+#pragma unroll
+                    for (int p = 0; p < kRP; ++p) facc[p] = __fadd_rn(facc[p], __fmul_rn(s_wcur[p], s_feat[tid * kRP + p]));
+                }
+            }
             // s_pt / s_raw are rewritten only after the next barrier pair; the owners' reads above are
             // ordered before their own writes at the top of the next iteration.
+        }
+        if (want_feat && tid < net.W / 2) {
+            for (int p = 0; p < kRP; ++p)
+                if (base + p < a.n_rays) a.out.feat_map[(base + p) * (net.W / 2) + tid] = facc[p];
         }
         if (live) {
             flags |= store_ray(a.out, ridx, comp, pass == 1, a.white_bkgd != 0);

@@ -884,7 +884,7 @@ struct Smem {
 __host__ __device__ inline bool is_lean(const RenderArgs& a) {
     const nwe_outputs& o = a.out;
     return !o.raw_coarse && !o.raw_fine && !o.z_fine && !o.weights_coarse && !o.disp && !o.z_std && !o.rgb_coarse && !o.depth_coarse &&
-           !o.acc_coarse && !o.disp_coarse && !o.sample_cond && !o.sample_amp && !o.sample_switch && !a.z_fine_in && !a.raw_in_c &&
+           !o.acc_coarse && !o.disp_coarse && !o.sample_cond && !o.sample_amp && !o.sample_switch && !o.feat_map && !a.z_fine_in && !a.raw_in_c &&
            !a.raw_in_f && !a.w_in && !a.t_rand && !a.noise_c && !a.noise_f && !a.u_rand && !a.stamps && !a.rays;
 }
 
@@ -894,7 +894,7 @@ __global__ void __launch_bounds__(256) render_mfma_kernel(RenderArgs a_in, NetMf
     if constexpr (LEAN) {
         a.out.raw_coarse = a.out.raw_fine = a.out.z_fine = a.out.weights_coarse = nullptr;
         a.out.disp = a.out.z_std = a.out.rgb_coarse = a.out.depth_coarse = a.out.acc_coarse = a.out.disp_coarse = nullptr;
-        a.out.sample_cond = a.out.sample_amp = a.out.sample_switch = nullptr;
+        a.out.sample_cond = a.out.sample_amp = a.out.sample_switch = a.out.feat_map = nullptr;
         a.z_fine_in = a.raw_in_c = a.raw_in_f = a.w_in = a.t_rand = a.noise_c = a.noise_f = a.u_rand = nullptr;
         a.stamps = nullptr; a.rays = nullptr;
     }

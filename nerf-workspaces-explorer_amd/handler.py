@@ -84,10 +84,10 @@ class NeRFReplicaInferenceHandler:
         self._img_h = cfg.get_param(("experiment", "image_height"), int)
         self._img_w = cfg.get_param(("experiment", "image_width"), int)
         self._depth_close_bound, self._depth_far_bound = cfg.get_param(("rendering", "depth_range"), list)
-        if not self._use_view_dirs:
-            raise NotImplementedError("only use_view_dirs=True networks are supported (all reference configs)")
-        if self._endpoint_feat:
-            raise NotImplementedError("endpoint_feat=True is not supported (False in every reference config)")
+        # rendering.use_view_dirs = False (nerf_model.py:41-43,82-83) and experiment.endpoint_feat = True (:72-81, handler.py:248-271)
+        # are off in all four reference YAMLs; both render here: networks without view directions through the fp32 HIP kernel
+        # (no MFMA instantiation), the endpoint feature map as `feat_map_fine` of _render_rays (fp32 kernel too; frames, which
+        # return rgb only, keep the MFMA kernel).
         self._fx, self._fy, self._cx, self._cy = pinhole_intrinsics(self._img_h, self._img_w)
         self._renderer: Optional[Renderer] = None
         self._stage: Optional[torch.Tensor] = None   # pinned uint8 [H,W,3] staging buffer for render_coordinates
@@ -117,6 +117,11 @@ class NeRFReplicaInferenceHandler:
         if getattr(self, "_fold", True) is False:
             self._renderer.debug_set_fold(False)
         coarse, fine = state_dicts
+        for name, sd in (("coarse", coarse), ("fine", fine)):
+            if sd is not None and any(k.lstrip("_").startswith("output_linear") for k in sd) == self._use_view_dirs:
+                # the reference would fail in load_state_dict(strict) (handler.py:134-141): say which side is off
+                raise RuntimeError(f"{name} network {'has no' if self._use_view_dirs else 'has'} view-direction heads but "
+                                   f"rendering.use_view_dirs is {self._use_view_dirs}")
         self._renderer.set_network(_lib.NET_COARSE, coarse)
         if fine is not None:
             self._renderer.set_network(_lib.NET_FINE, fine)
@@ -214,12 +219,16 @@ class NeRFReplicaInferenceHandler:
         Renderer.render_rays."""
         r = self._need_renderer()
         fine = self._n_importance > 0
+        precision = precision or self._precision
         if outputs is None:
             outputs = ["rgb", "disp", "acc", "depth", "rgb_coarse", "disp_coarse", "acc_coarse", "depth_coarse"]
             if fine:
                 outputs.append("z_std")
-        res = r.render_rays(flat_rays, precision=precision or self._precision, outputs=outputs, train=train)
-        rename = {"rgb": "rgb_fine", "disp": "disp_fine", "acc": "acc_fine", "depth": "depth_fine"}
+            if fine and self._endpoint_feat and self._use_view_dirs:      # handler.py:270-271
+                outputs.append("feat_map")
+                precision = "f32"                                         # the composited view-layer features exist in the fp32 kernel only
+        res = r.render_rays(flat_rays, precision=precision, outputs=outputs, train=train)
+        rename = {"rgb": "rgb_fine", "disp": "disp_fine", "acc": "acc_fine", "depth": "depth_fine", "feat_map": "feat_map_fine"}
         return {rename.get(k, k): v for k, v in res.items() if not k.startswith("_")}
 
     # ------------------------------------------------------------------------------------------------

@@ -39,7 +39,8 @@ def net_shape(sd: Mapping[str, np.ndarray]) -> Tuple[int, int, int, int, int]:
     if D == 0:
         raise ValueError("state dict has no _pts_linears.0.weight")
     W, in_xyz = sd["_pts_linears.0.weight"].shape
-    in_dir = sd["_views_linears.0.weight"].shape[1] - W
+    # use_view_dirs=False (nerf_model.py:41-43): `_output_linear` instead of the alpha / feature / rgb heads, no direction input
+    in_dir = 0 if "_output_linear.weight" in sd else sd["_views_linears.0.weight"].shape[1] - W
     skip = -1
     for i in range(1, D):
         k = sd[f"_pts_linears.{i}.weight"].shape[1]
@@ -88,19 +89,34 @@ class Renderer:
     def set_network(self, which: int, state_dict: Mapping[str, object]) -> Tuple[int, int, int, int, int]:
         sd = normalize_state_dict(state_dict)
         D, W, in_xyz, in_dir, skip = net_shape(sd)
-        names = [f"_pts_linears.{i}" for i in range(D)] + list(LAYER_ORDER_TAIL)
+        if in_dir == 0:     # NeRFModel(use_view_dirs=False): trunk + _output_linear (nerf_model.py:41-43,82-83)
+            names = [f"_pts_linears.{i}" for i in range(D)] + ["_output_linear"]
+            out_ch = int(sd["_output_linear.weight"].shape[0])
+            expect_in = [in_xyz] + [W + in_xyz if i - 1 == skip else W for i in range(1, D)] + [W]
+            expect_out = [W] * D + [out_ch]
+        else:
+            names = [f"_pts_linears.{i}" for i in range(D)] + list(LAYER_ORDER_TAIL)
+            expect_in = [in_xyz] + [W + in_xyz if i - 1 == skip else W for i in range(1, D)] + [W + in_dir, W, W, W // 2]
+            expect_out = [W] * D + [W // 2, W, 1, 3]
         ws = [sd[n + ".weight"] for n in names]
         bs = [sd[n + ".bias"] for n in names]
-        expect_in = [in_xyz] + [W + in_xyz if i - 1 == skip else W for i in range(1, D)] + [W + in_dir, W, W, W // 2]
-        expect_out = [W] * D + [W // 2, W, 1, 3]
         for n, w, b, ki, ko in zip(names, ws, bs, expect_in, expect_out):
             if w.shape != (ko, ki) or b.shape != (ko,):
                 raise ValueError(f"{n}: expected weight [{ko},{ki}] and bias [{ko}], got {w.shape} / {b.shape}")
         wp = (C.c_void_p * len(ws))(*[w.ctypes.data for w in ws])
         bp = (C.c_void_p * len(bs))(*[b.ctypes.data for b in bs])
-        self._check(self._lib.nwe_set_network(self._ctx, which, D, W, in_xyz, in_dir, skip, wp, bp), "nwe_set_network")
+        if in_dir == 0:
+            self._check(self._lib.nwe_set_network_no_view_dirs(self._ctx, which, D, W, in_xyz, skip, out_ch, wp, bp),
+                        "nwe_set_network_no_view_dirs")
+        else:
+            self._check(self._lib.nwe_set_network(self._ctx, which, D, W, in_xyz, in_dir, skip, wp, bp), "nwe_set_network")
         self.shapes[which] = (D, W, in_xyz, in_dir, skip)
         return self.shapes[which]
+
+    @property
+    def ray_columns(self) -> int:
+        """11 ([o d near far viewdir], rays.py:26-30), or 8 when the networks take no view directions (rays.py:22)."""
+        return 8 if self.shapes.get(_lib.NET_COARSE, (0, 0, 0, 27, 0))[3] == 0 else 11
 
     def set_sampling(self, n_samples: int, n_importance: int) -> None:
         """Tables come from torch.linspace on the host, whose bits differ from i/(n-1)."""
@@ -127,6 +143,8 @@ class Renderer:
                 shape = (n_rays, S, 4)
             elif name == "z_fine":
                 shape = (n_rays, S)
+            elif name == "feat_map":
+                shape = (n_rays, self.shapes[_lib.NET_FINE][1] // 2)
             else:
                 raise ValueError(f"unknown output {name!r}")
             res[name] = torch.empty(shape, dtype=torch.float32, device=self.device)
@@ -152,8 +170,9 @@ class Renderer:
         return res
 
     def create_rays(self, c2w, H: int, W: int, *, fx: float, fy: float, cx: float, cy: float, near: float, far: float,
-                    rows: Optional[Tuple[int, int]] = None) -> torch.Tensor:
-        """[B*(rows)*W, 11] device rays, the layout and bits of nerf/rays/rays.py:6-32."""
+                    rows: Optional[Tuple[int, int]] = None, use_view_dirs: bool = True) -> torch.Tensor:
+        """[B*(rows)*W, 11] device rays, the layout and bits of nerf/rays/rays.py:6-32; use_view_dirs=False leaves the
+        view-direction columns out ([.., 8], rays.py:22-30)."""
         poses = np.ascontiguousarray(np.asarray(c2w, dtype=np.float32).reshape(-1, 4, 4))
         r0, r1 = rows if rows is not None else (0, H)
         with torch.cuda.device(self.device):
@@ -162,7 +181,7 @@ class Renderer:
             rc = self._lib.nwe_create_rays(self._ctx, poses.ctypes.data, poses.shape[0], H, W, fx, fy, cx, cy, near, far, r0, r1,
                                            out.data_ptr(), stream)
         self._check(rc, "nwe_create_rays")
-        return out
+        return out if use_view_dirs else out[:, :8].contiguous()
 
     def render_rays(self, rays: torch.Tensor, *, precision: str = "f16x3",
                     outputs: Sequence[str] = ("rgb", "depth", "acc"),
@@ -180,8 +199,8 @@ class Renderer:
         ``t_rand`` [R,Ns] = torch.rand (stratified jitter), ``noise_coarse`` [R,Ns] and ``noise_fine`` [R,Ns+Ni] =
         torch.randn * raw_noise_std (model_utils.py:64-71), ``u`` [R,Ni] = torch.rand of sample_pdf(det=False)
         (rays.py:98; sorted per ray here, which changes no output because the depths are sorted afterwards)."""
-        if rays.dim() != 2 or rays.shape[1] != 11 or rays.dtype != torch.float32:
-            raise ValueError("rays must be float32 [R,11]")
+        if rays.dim() != 2 or rays.shape[1] != self.ray_columns or rays.dtype != torch.float32:
+            raise ValueError(f"rays must be float32 [R,{self.ray_columns}] for these networks")
         rays = rays.to(self.device).contiguous()
         if debug_fine_depths is not None:
             debug_fine_depths = debug_fine_depths.to(self.device, torch.float32).contiguous()

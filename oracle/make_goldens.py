@@ -38,7 +38,7 @@ _spec = importlib.util.spec_from_file_location(
 synthetic = importlib.util.module_from_spec(_spec)
 _spec.loader.exec_module(synthetic)
 
-GOLD = os.path.join(ROOT, "tests", "golden")
+GOLD = os.environ.get("NWE_GOLD_DIR") or os.path.join(ROOT, "tests", "golden")   # NWE_GOLD_DIR: re-generate into a scratch directory to verify
 torch.set_grad_enabled(False)
 
 # the two C3 poses of SURVEY.md §8(d): office_tokyo click (0.5, 0.5), hor = 0 and hor = 30
@@ -318,6 +318,100 @@ def main() -> None:
     train["e2e_z_fine_first64"] = res["z_fine"][:64].numpy()
     train["e2e_sigma_last_fine"] = (res["raw_fine"][:, -1, 3] + tr["noise_fine"][:, -1]).numpy()
     np.savez_compressed(os.path.join(GOLD, "train_mode.npz"), **train)
+
+    # (10) the model variants of nerf_model.py:41-43,72-83 --------------------------------------------
+    # use_view_dirs=False: the handler builds NeRFModel(input_ch_views=0, output_ch=5, use_view_dirs=False) (handler.py:97-119),
+    # create_rays leaves the view-direction columns out (rays.py:22-30) and run_network embeds no directions.
+    # endpoint_feat=True: the FINE network is called with show_endpoint (handler.py:248), raw_fine carries the view layer's
+    # W/2 = 128 outputs behind [rgb, sigma] and raw2outputs composites them too (model_utils.py:87-89).
+    print("[10] model variants: use_view_dirs=False, endpoint_feat=True")
+    var = {}
+    x63 = e3.embed(pts).repeat(2, 1)                                                                  # [512, 63]
+    for tag, (D, W, seed) in {"4x128": (4, 128, 2000), "8x256": (8, 256, 2001)}.items():
+        sd = synthetic.make_state_dict(seed, D, W, use_view_dirs=False)
+        m = NeRFModel(D=D, W=W, input_ch=63, output_ch=5, input_ch_views=0, use_view_dirs=False)
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+        ref = m.eval()(x63)
+        same(O.mlp_forward({k: torch.from_numpy(v) for k, v in sd.items()}, x63), ref, f"mlp without view dirs {tag}")
+        var[f"novd_y_{tag}"] = ref.numpy()
+    var["novd_x"] = x63.numpy()
+    # end to end, 8-column rays, 8x256 coarse + fine, 16 + 24 samples on 256 rays of the 800x800 frame
+    sd_c8, sd_f8 = synthetic.thin_fog_output(synthetic.make_state_dict(2001, 8, 256, use_view_dirs=False)), synthetic.make_state_dict(2002, 8, 256, use_view_dirs=False)
+    nets = []
+    for sd in (sd_c8, sd_f8):
+        m = NeRFModel(D=8, W=256, input_ch=63, output_ch=5, input_ch_views=0, use_view_dirs=False)
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+        nets.append(m.eval())
+    full8 = ref_create_rays(1, POSES["hor30"], 800, 800, fx, fy, cx, cy, 0.1, 10.0, False)[0]
+    same(O.create_rays(POSES["hor30"], 800, 800, fx, fy, cx, cy, 0.1, 10.0, False)[0], full8, "create_rays without view dirs")
+    idx10 = (torch.arange(256) * 2477 + 3) % (800 * 800)
+    rays8 = full8[idx10].contiguous()
+    assert rays8.shape[1] == 8
+    e3n = Embedding(10, scalar_factor=10)
+
+    def ref_render_novd(rb):
+        ro, rd = rb[:, 0:3], rb[:, 3:6]
+        vd = rb[:, -3:] if rb.shape[-1] > 8 else None                                                  # handler.py:211
+        bounds = torch.reshape(rb[..., 6:8], [-1, 1, 2])
+        near, far = bounds[..., 0], bounds[..., 1]
+        t_vals = torch.linspace(0., 1., steps=16)
+        zv = (near * (1. - t_vals) + far * (t_vals)).expand([rb.shape[0], 16])
+        p = ro[..., None, :] + rd[..., None, :] * zv[..., :, None]
+        raw_c = ref_run_network(p, vd, nets[0], e3n.embed, None, netchunk=1024 * 32)
+        rgb_c, disp_c, acc_c, w_c, depth_c, _ = ref_raw2outputs(raw_c, zv, rd, 0, False, endpoint_feat=False, cuda_enabled=False)
+        zs = ref_sample_pdf(.5 * (zv[..., 1:] + zv[..., :-1]), w_c[..., 1:-1], 24, det=True)
+        za, _ = torch.sort(torch.cat([zv, zs], -1), -1)
+        pf = ro[..., None, :] + rd[..., None, :] * za[..., :, None]
+        raw_f = ref_run_network(pf, vd, lambda x: nets[1](x, False), e3n.embed, None, netchunk=1024 * 32)
+        rgb_f, disp_f, acc_f, w_f, depth_f, _ = ref_raw2outputs(raw_f, za, rd, 0, False, endpoint_feat=False, cuda_enabled=False)
+        return dict(rgb_coarse=rgb_c, depth_coarse=depth_c, acc_coarse=acc_c, raw_coarse=raw_c, rgb_fine=rgb_f, depth_fine=depth_f,
+                    acc_fine=acc_f, disp_fine=disp_f, raw_fine=raw_f, z_fine=za, z_std=torch.std(zs, dim=-1, unbiased=False))
+
+    ref = ref_render_novd(rays8)
+    mine = O.render_rays(rays8, {k: torch.from_numpy(v) for k, v in sd_c8.items()}, {k: torch.from_numpy(v) for k, v in sd_f8.items()},
+                         O.RenderConfig(n_samples=16, n_importance=24))
+    for k in ref:
+        same(mine[k], ref[k], f"no view dirs, end to end: {k}")
+    assert ref["raw_fine"].shape[-1] == 5
+    var.update({"novd_idx": idx10.numpy(), "novd_pose": POSES["hor30"][0].numpy(), "novd_rays_first4": rays8[:4].numpy()})
+    for k in ("rgb_fine", "depth_fine", "acc_fine", "z_std", "rgb_coarse", "depth_coarse", "acc_coarse", "z_fine"):
+        var["novd_" + k] = ref[k].numpy()
+    var["novd_raw_fine_first32"] = ref["raw_fine"][:32].numpy()
+    var["novd_sigma_last_fine"] = ref["raw_fine"][:, -1, 3].numpy()
+    # endpoint_feat: the 8x256 view-dirs networks of the fog scene, 256 rays, 16 + 24 samples
+    x90 = torch.cat([e3.embed(pts), e2.embed(dirs)], -1).repeat(2, 1)
+    refe = net_f(x90, True)
+    same(O.mlp_forward(tf, x90, True), refe, "mlp with show_endpoint")
+    assert refe.shape[-1] == 4 + 128
+    var["ep_y_8x256"] = refe.numpy()
+    rays11 = full[idx10].contiguous()
+
+    def ref_render_ep(rb):
+        ro, rd, vd = rb[:, 0:3], rb[:, 3:6], rb[:, -3:]
+        bounds = torch.reshape(rb[..., 6:8], [-1, 1, 2])
+        near, far = bounds[..., 0], bounds[..., 1]
+        t_vals = torch.linspace(0., 1., steps=16)
+        zv = (near * (1. - t_vals) + far * (t_vals)).expand([rb.shape[0], 16])
+        p = ro[..., None, :] + rd[..., None, :] * zv[..., :, None]
+        raw_c = ref_run_network(p, vd, net_fog, e3.embed, e2.embed, netchunk=1024 * 32)
+        _, _, _, w_c, _, _ = ref_raw2outputs(raw_c, zv, rd, 0, False, endpoint_feat=False, cuda_enabled=False)
+        zs = ref_sample_pdf(.5 * (zv[..., 1:] + zv[..., :-1]), w_c[..., 1:-1], 24, det=True)
+        za, _ = torch.sort(torch.cat([zv, zs], -1), -1)
+        pf = ro[..., None, :] + rd[..., None, :] * za[..., :, None]
+        raw_f = ref_run_network(pf, vd, lambda x: net_f(x, True), e3.embed, e2.embed, netchunk=1024 * 32)       # handler.py:248
+        rgb_f, disp_f, acc_f, w_f, depth_f, feat = ref_raw2outputs(raw_f, za, rd, 0, False, endpoint_feat=True, cuda_enabled=False)
+        return dict(rgb_fine=rgb_f, depth_fine=depth_f, acc_fine=acc_f, feat_map_fine=feat, raw_fine=raw_f, z_fine=za)
+
+    ref = ref_render_ep(rays11)
+    mine = O.render_rays(rays11, {k: torch.from_numpy(v) for k, v in sd_fog.items()}, tf,
+                         O.RenderConfig(n_samples=16, n_importance=24, endpoint_feat=True))
+    for k in ref:
+        same(mine[k], ref[k], f"endpoint_feat, end to end: {k}")
+    assert ref["feat_map_fine"].shape == (256, 128) and ref["raw_fine"].shape[-1] == 132
+    for k in ("rgb_fine", "depth_fine", "acc_fine", "feat_map_fine", "z_fine"):
+        var["ep_" + k] = ref[k].numpy()
+    var["ep_sigma_last_fine"] = ref["raw_fine"][:, -1, 3].numpy()
+    np.savez_compressed(os.path.join(GOLD, "variants.npz"), **var)
     print("goldens written to", GOLD)
 
 

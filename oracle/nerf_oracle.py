@@ -157,15 +157,16 @@ def net_shape(state: Dict[str, torch.Tensor]) -> Tuple[int, int, int, int, Tuple
         D += 1
     W = state["_pts_linears.0.weight"].shape[0]
     in_xyz = state["_pts_linears.0.weight"].shape[1]
-    in_dir = state["_views_linears.0.weight"].shape[1] - W
+    # use_view_dirs=False (nerf_model.py:41-43): _output_linear instead of the alpha/feature/rgb heads, no direction input
+    in_dir = 0 if "_output_linear.weight" in state else state["_views_linears.0.weight"].shape[1] - W
     skips = tuple(i - 1 for i in range(1, D) if state[f"_pts_linears.{i}.weight"].shape[1] == W + in_xyz)
     return D, W, in_xyz, in_dir, skips
 
 
-def mlp_forward(state: Dict[str, torch.Tensor], x: torch.Tensor) -> torch.Tensor:
-    """[P, in_xyz+in_dir] -> [P, 4] = [rgb_raw(3), sigma_raw(1)].
-
-    nerf/models/nerf_model.py:45-83 with use_view_dirs=True, show_endpoint=False.
+def mlp_forward(state: Dict[str, torch.Tensor], x: torch.Tensor, show_endpoint: bool = False) -> torch.Tensor:
+    """[P, in_xyz+in_dir] -> [P, 4] = [rgb_raw(3), sigma_raw(1)]   (use_view_dirs=True, nerf/models/nerf_model.py:45-83)
+                          -> [P, output_ch]                        (use_view_dirs=False: _output_linear(h), :82-83)
+    show_endpoint (use_view_dirs=True only, :72-73,:78-79): the view layer's output (W/2) is appended.
     The skip concatenation happens AFTER the ReLU of layer index `skip` (:55-59).
     """
     D, W, in_xyz, in_dir, skips = net_shape(state)
@@ -175,23 +176,27 @@ def mlp_forward(state: Dict[str, torch.Tensor], x: torch.Tensor) -> torch.Tensor
         h = F.relu(F.linear(h, state[f"_pts_linears.{i}.weight"], state[f"_pts_linears.{i}.bias"]))
         if i in skips:
             h = torch.cat([pts, h], -1)
+    if "_output_linear.weight" in state:
+        return F.linear(h, state["_output_linear.weight"], state["_output_linear.bias"])     # :83
     alpha = F.linear(h, state["_alpha_linear.weight"], state["_alpha_linear.bias"])          # :63
     feature = F.linear(h, state["_feature_linear.weight"], state["_feature_linear.bias"])    # :64
     g = torch.cat([feature, views], -1)                                                      # :66
     g = F.relu(F.linear(g, state["_views_linears.0.weight"], state["_views_linears.0.bias"]))  # :68-70
     rgb = F.linear(g, state["_rgb_linear.weight"], state["_rgb_linear.bias"])                # :74
-    return torch.cat([rgb, alpha], -1)                                                       # :76
+    out = torch.cat([rgb, alpha], -1)                                                        # :76
+    return torch.cat([out, g], -1) if show_endpoint else out                                 # :78-81
 
 
-def run_network(pts: torch.Tensor, viewdirs: torch.Tensor, state: Dict[str, torch.Tensor],
-                freqs_xyz: int, freqs_dir: int, netchunk: int) -> torch.Tensor:
-    """[N,S,3] points + [N,3] view dirs -> raw [N,S,4].  nerf/models/model_utils.py:13-30 and
-    utils/batch_utils.py:28-39 (the point-chunk loop)."""
+def run_network(pts: torch.Tensor, viewdirs: Optional[torch.Tensor], state: Dict[str, torch.Tensor],
+                freqs_xyz: int, freqs_dir: int, netchunk: int, show_endpoint: bool = False) -> torch.Tensor:
+    """[N,S,3] points + [N,3] view dirs (None: 8-column rays of use_view_dirs=False) -> raw [N,S,C].
+    nerf/models/model_utils.py:13-30 and utils/batch_utils.py:28-39 (the point-chunk loop)."""
     flat = pts.reshape(-1, 3)
     enc = embed(flat, freqs_xyz, 10)                                 # handler.py:93 (scalar_factor=10)
-    dirs = viewdirs[:, None].expand(pts.shape).reshape(-1, 3)        # model_utils.py:23-24
-    enc = torch.cat([enc, embed(dirs, freqs_dir, 1)], -1)            # handler.py:101 (scalar_factor=1)
-    out = torch.cat([mlp_forward(state, enc[i:i + netchunk]) for i in range(0, enc.shape[0], netchunk)], 0)
+    if viewdirs is not None:                                         # model_utils.py:22
+        dirs = viewdirs[:, None].expand(pts.shape).reshape(-1, 3)    # :23-24
+        enc = torch.cat([enc, embed(dirs, freqs_dir, 1)], -1)        # handler.py:101 (scalar_factor=1)
+    out = torch.cat([mlp_forward(state, enc[i:i + netchunk], show_endpoint) for i in range(0, enc.shape[0], netchunk)], 0)
     return out.reshape(list(pts.shape[:-1]) + [out.shape[-1]])
 
 
@@ -201,7 +206,7 @@ def run_network(pts: torch.Tensor, viewdirs: torch.Tensor, state: Dict[str, torc
 
 
 def raw2outputs(raw: torch.Tensor, z_vals: torch.Tensor, rays_d: torch.Tensor, white_bkgd: bool = False,
-                noise: Optional[torch.Tensor] = None):
+                noise: Optional[torch.Tensor] = None, endpoint_feat: bool = False):
     """raw [N,S,4], z [N,S], d [N,3] -> rgb [N,3], disp [N], acc [N], weights [N,S], depth [N].
 
     model_utils.py:49-100 on the cuda_enabled=False branch; `noise` [N,S] is the reference's
@@ -220,6 +225,8 @@ def raw2outputs(raw: torch.Tensor, z_vals: torch.Tensor, rays_d: torch.Tensor, w
     acc_map = torch.sum(weights, -1)                                                 # :95
     if white_bkgd:
         rgb_map = rgb_map + (1. - acc_map[..., None])                                # :98
+    if endpoint_feat:                                                                # :87-89: the LAST 128 channels, whatever the width
+        return rgb_map, disp_map, acc_map, weights, depth_map, torch.sum(weights[..., None] * raw[..., -128:], -2)
     return rgb_map, disp_map, acc_map, weights, depth_map
 
 
@@ -232,10 +239,11 @@ class RenderConfig:
     """The handler fields the render loop reads (handler.py:39-78), with the YAML defaults."""
 
     def __init__(self, n_samples: int = 64, n_importance: int = 128, freqs_xyz: int = 10, freqs_dir: int = 4,
-                 net_chunk: int = 1024 * 32, chunk: int = 1024 * 8, white_bkgd: bool = False):
+                 net_chunk: int = 1024 * 32, chunk: int = 1024 * 8, white_bkgd: bool = False, endpoint_feat: bool = False):
         self.n_samples, self.n_importance = n_samples, n_importance
         self.freqs_xyz, self.freqs_dir = freqs_xyz, freqs_dir
         self.net_chunk, self.chunk, self.white_bkgd = net_chunk, chunk, white_bkgd
+        self.endpoint_feat = endpoint_feat                       # experiment.endpoint_feat (handler.py:41): fine pass only, :248,:254
 
 
 def volumetric_rendering(ray_batch: torch.Tensor, coarse: Dict[str, torch.Tensor],
@@ -253,7 +261,8 @@ def volumetric_rendering(ray_batch: torch.Tensor, coarse: Dict[str, torch.Tensor
     sample_pdf's det=False branch are pinned against the reference by tests/golden/train_mode.npz.
     """
     train = train or {}
-    rays_o, rays_d, viewdirs = ray_batch[:, 0:3], ray_batch[:, 3:6], ray_batch[:, -3:]   # :210-211
+    rays_o, rays_d = ray_batch[:, 0:3], ray_batch[:, 3:6]                                 # :210
+    viewdirs = ray_batch[:, -3:] if ray_batch.shape[-1] > 8 else None                     # :211 (8 columns: use_view_dirs=False)
     bounds = ray_batch[..., 6:8].reshape(-1, 1, 2)
     near, far = bounds[..., 0], bounds[..., 1]                                            # :213-214
     t_vals = torch.linspace(0., 1., steps=cfg.n_samples)                                  # :216
@@ -274,8 +283,11 @@ def volumetric_rendering(ray_batch: torch.Tensor, coarse: Dict[str, torch.Tensor
         z_samples = sample_pdf(z_mid, w_c[..., 1:-1], cfg.n_importance, train.get("u"))   # :237 (always det in inference)
         z_all, _ = torch.sort(torch.cat([z_vals, z_samples], -1), -1)                     # :243
         pts_f = rays_o[..., None, :] + rays_d[..., None, :] * z_all[..., :, None]         # :246
-        raw_f = run_network(pts_f, viewdirs, fine, cfg.freqs_xyz, cfg.freqs_dir, cfg.net_chunk)
-        rgb_f, disp_f, acc_f, w_f, depth_f = raw2outputs(raw_f, z_all, rays_d, cfg.white_bkgd, train.get("noise_fine"))
+        raw_f = run_network(pts_f, viewdirs, fine, cfg.freqs_xyz, cfg.freqs_dir, cfg.net_chunk, cfg.endpoint_feat)   # :248
+        r2o = raw2outputs(raw_f, z_all, rays_d, cfg.white_bkgd, train.get("noise_fine"), cfg.endpoint_feat)          # :252-254
+        rgb_f, disp_f, acc_f, w_f, depth_f = r2o[:5]
+        if cfg.endpoint_feat:
+            out["feat_map_fine"] = r2o[5]                                                 # :270-271
         out.update({"rgb_fine": rgb_f, "disp_fine": disp_f, "acc_fine": acc_f, "depth_fine": depth_f,
                     "z_std": torch.std(z_samples, dim=-1, unbiased=False),                # :267
                     "raw_fine": raw_f, "z_fine": z_all, "z_samples": z_samples})

@@ -1180,3 +1180,118 @@ def test_in_process_tiles_edge_cases():
     assert torch.cuda.current_device() == 0
     for r in (one, tiled, broken):
         r.close()
+
+
+def _variant_rays(g, use_view_dirs):
+    fx, fy, cx, cy = O.intrinsics(800, 800)
+    pose = torch.from_numpy(g["novd_pose"])[None]
+    return O.create_rays(pose, 800, 800, fx, fy, cx, cy, 0.1, 10.0, use_view_dirs)[0][torch.from_numpy(g["novd_idx"])].contiguous()
+
+
+def test_networks_without_view_dirs(golden_dir, tmp_path, monkeypatch, capsys):
+    """NeRFModel(use_view_dirs=False) (nerf_model.py:41-43,82-83): trunk + _output_linear [5, W], 8-column rays (rays.py:22-30),
+    against tests/golden/variants.npz (the reference's own classes): the network alone at the embed.npz points, then 16 + 24
+    samples end to end with a thin-fog coarse network (every ray at full tolerance); the fp32 HIP kernel serves it (no MFMA
+    instantiation - asked for explicitly it is refused, never silently replaced), also through the handler with
+    rendering.use_view_dirs: False in its YAML."""
+    g = np.load(os.path.join(golden_dir, "variants.npz"))
+    ge = np.load(os.path.join(golden_dir, "embed.npz"))
+    pts = np.concatenate([ge["pts"]] * 2, 0)
+    rays_pts = torch.from_numpy(np.concatenate([pts, np.ones_like(pts), np.zeros((pts.shape[0], 2), np.float32)], 1).astype(np.float32)).cuda()
+    for tag, D, Wn, seed in (("4x128", 4, 128, 2000), ("8x256", 8, 256, 2001)):
+        r = nwe_amd.Renderer(0)
+        assert r.set_network(0, nwe_amd.synthetic.make_state_dict(seed, D, Wn, use_view_dirs=False))[3] == 0 and r.ray_columns == 8
+        assert not r.mfma_supported(0)
+        r.set_sampling(2, 0)
+        raw = r.render_rays(rays_pts, precision="f32", outputs=("raw_coarse",))["raw_coarse"].cpu().numpy()
+        err = np.abs(raw[:, 0] - g[f"novd_y_{tag}"][:, :4]).max()
+        print(f"[no view dirs {tag}] raw vs the reference's NeRFModel: {err:.2e}")
+        assert err <= 5e-6
+        with pytest.raises(NotImplementedError):
+            r.render_rays(rays_pts, precision="f16x3", outputs=("raw_coarse",))
+        with pytest.raises(ValueError, match="R,8"):
+            r.render_rays(torch.zeros(4, 11, device="cuda"), precision="f32")
+        r.close()
+    sd_c = nwe_amd.synthetic.thin_fog_output(nwe_amd.synthetic.make_state_dict(2001, 8, 256, use_view_dirs=False))
+    sd_f = nwe_amd.synthetic.make_state_dict(2002, 8, 256, use_view_dirs=False)
+    rays8 = _variant_rays(g, False)
+    r = nwe_amd.Renderer(0)
+    r.set_network(0, sd_c); r.set_network(1, sd_f); r.set_sampling(16, 24)
+    out = r.render_rays(rays8.cuda(), precision="f32", outputs=("rgb", "depth", "acc", "z_std", "rgb_coarse", "depth_coarse", "acc_coarse", "z_fine", "raw_fine"))
+    cliff = np.abs(g["novd_sigma_last_fine"]) < 1e-5
+    errs = {k: float(np.abs(out[k].cpu().numpy() - g["novd_" + n])[~cliff].max()) for k, n in
+            (("rgb", "rgb_fine"), ("depth", "depth_fine"), ("acc", "acc_fine"), ("z_std", "z_std"), ("rgb_coarse", "rgb_coarse"),
+             ("depth_coarse", "depth_coarse"), ("acc_coarse", "acc_coarse"), ("z_fine", "z_fine"))}
+    print("[no view dirs, end to end]", {k: f"{v:.1e}" for k, v in errs.items()})
+    assert errs["rgb"] <= RGB_TOL and errs["rgb_coarse"] <= RGB_TOL and errs["depth"] / FAR <= 1e-4 and errs["acc"] <= 1e-4
+    assert errs["z_fine"] <= 1e-4 and errs["z_std"] <= 1e-4
+    assert np.abs(out["raw_fine"].cpu().numpy()[:32] - g["novd_raw_fine_first32"][..., :4]).max() <= 2e-4   # at slightly moved depths
+    # create_rays without the view-direction columns: the first eight columns, bit for bit
+    fx, fy, cx, cy = O.intrinsics(800, 800)
+    mine = r.create_rays(g["novd_pose"], 800, 800, fx=fx, fy=fy, cx=cx, cy=cy, near=0.1, far=10.0, rows=(0, 2), use_view_dirs=False)
+    assert mine.shape[1] == 8 and torch.equal(mine.cpu(), O.create_rays(torch.from_numpy(g["novd_pose"])[None], 800, 800, fx, fy, cx, cy, 0.1, 10.0, False)[0][:1600])
+    # a context must not mix the two kinds of network
+    r.set_network(1, nwe_amd.synthetic.make_state_dict(1001, 8, 256))
+    with pytest.raises(RuntimeError, match="both have, or both lack"):
+        r.render_rays(rays8.cuda(), precision="f32")
+    r.close()
+    # through the handler: a YAML with use_view_dirs: False
+    import yaml
+    cfg = {k: dict(v) for k, v in nwe_amd.config.INFERENCE_DEFAULTS.items()}
+    cfg["rendering"].update(use_view_dirs=False, n_samples=16, n_importance=24)
+    cfg["experiment"].update(image_width=24, image_height=16)
+    with open(tmp_path / "office_tokyo_config.yaml", "w") as f:
+        yaml.safe_dump(cfg, f)
+    monkeypatch.setenv("NWE_CONFIG_DIR", str(tmp_path))
+    h = nwe_amd.NeRFReplicaInferenceHandler("office_tokyo", "synthetic")
+    with pytest.raises(RuntimeError, match="view-direction heads"):
+        h.initialize_models(state_dicts=(_sd(1000, 8, 256), _sd(1001, 8, 256)))
+    h.initialize_models(state_dicts=(sd_c, sd_f))
+    assert "no MFMA instantiation" in capsys.readouterr().out
+    res = h._render_rays(rays8.cuda())
+    assert np.abs(res["rgb_fine"].cpu().numpy() - g["novd_rgb_fine"])[~cliff].max() <= RGB_TOL
+    init, loc = nwe_amd.COORD(x=0.0, y=-0.5, z=-0.76, pitch=-90.0), nwe_amd.COORD(yaw=-30.0)
+    img = h.render_coordinates(init, loc)
+    pose = nwe_amd.get_camera_poses_from_list_of_coordinates(init, [loc])
+    fx, fy, cx, cy = O.intrinsics(16, 24)
+    ref = O.render_rays(O.create_rays(pose, 16, 24, fx, fy, cx, cy, 0.1, 10.0, False)[0], _t(sd_c), _t(sd_f), O.RenderConfig(n_samples=16, n_importance=24))
+    assert img.shape == (16, 24, 3) and np.abs(img.astype(int) - O.to8b(ref["rgb_fine"].numpy().reshape(16, 24, 3)).astype(int)).max() <= 1
+
+
+def test_endpoint_feature_map(golden_dir, tmp_path, monkeypatch):
+    """experiment.endpoint_feat = True: the fine network is evaluated with show_endpoint (handler.py:248; nerf_model.py:72-81) and
+    the view layer's 128 outputs are composited like rgb (model_utils.py:87-89) into feat_map_fine (handler.py:270-271).  The fp32
+    HIP kernel against the reference's own result (variants.npz); the MFMA kernel refuses the output; the handler's _render_rays
+    carries the key when the YAML says so, and its frames (rgb only) stay on the MFMA kernel."""
+    g = np.load(os.path.join(golden_dir, "variants.npz"))
+    rays11 = _variant_rays(g, True).cuda()
+    sd_c, sd_f = nwe_amd.synthetic.thin_fog(_sd(1000, 8, 256)), _sd(1001, 8, 256)
+    r = nwe_amd.Renderer(0)
+    r.set_network(0, sd_c); r.set_network(1, sd_f); r.set_sampling(16, 24)
+    out = r.render_rays(rays11, precision="f32", outputs=("rgb", "depth", "acc", "feat_map", "z_fine"))
+    cliff = np.abs(g["ep_sigma_last_fine"]) < 1e-5
+    e_feat = np.abs(out["feat_map"].cpu().numpy() - g["ep_feat_map_fine"])[~cliff]
+    print(f"[endpoint_feat] feat_map_fine vs reference: max {e_feat.max():.2e} (|feat| max {np.abs(g['ep_feat_map_fine']).max():.2f}); "
+          f"rgb {np.abs(out['rgb'].cpu().numpy() - g['ep_rgb_fine'])[~cliff].max():.2e}, z {np.abs(out['z_fine'].cpu().numpy() - g['ep_z_fine']).max():.1e}")
+    assert out["feat_map"].shape == (256, 128)
+    assert e_feat.max() <= 1e-4 * max(1.0, float(np.abs(g["ep_feat_map_fine"]).max()))
+    assert np.abs(out["rgb"].cpu().numpy() - g["ep_rgb_fine"])[~cliff].max() <= RGB_TOL
+    assert np.abs(out["depth"].cpu().numpy() - g["ep_depth_fine"])[~cliff].max() / FAR <= 1e-4
+    with pytest.raises(NotImplementedError, match="F32"):
+        r.render_rays(rays11, precision="f16x3", outputs=("rgb", "feat_map"))
+    r.set_sampling(16, 0)
+    with pytest.raises(ValueError, match="n_importance"):
+        r.render_rays(rays11, precision="f32", outputs=("rgb", "feat_map"))
+    r.close()
+    import yaml
+    cfg = {k: dict(v) for k, v in nwe_amd.config.INFERENCE_DEFAULTS.items()}
+    cfg["rendering"].update(n_samples=16, n_importance=24)
+    cfg["experiment"].update(endpoint_feat=True)
+    with open(tmp_path / "office_tokyo_config.yaml", "w") as f:
+        yaml.safe_dump(cfg, f)
+    monkeypatch.setenv("NWE_CONFIG_DIR", str(tmp_path))
+    h = nwe_amd.NeRFReplicaInferenceHandler("office_tokyo", "synthetic")
+    h.initialize_models(state_dicts=(sd_c, sd_f))
+    res = h._render_rays(rays11)
+    assert np.abs(res["feat_map_fine"].cpu().numpy() - g["ep_feat_map_fine"])[~cliff].max() <= 1e-4 * max(1.0, float(np.abs(g["ep_feat_map_fine"]).max()))
+    assert h._precision == "f16x3"                       # frames (rgb only, handler.py:180) keep the MFMA kernel

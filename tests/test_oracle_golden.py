@@ -175,3 +175,39 @@ def test_training_mode_end_to_end_small(golden_dir):
     lo, hi = np.concatenate([base[:1], mids]), np.concatenate([mids, base[-1:]])
     zc = g["e2e_z_coarse"]
     assert (zc >= lo - 1e-6).all() and (zc <= hi + 1e-6).all() and np.abs(zc - base).max() > 1e-2
+
+
+def test_model_variants(golden_dir):
+    """tests/golden/variants.npz: NeRFModel(use_view_dirs=False) (nerf_model.py:41-43,82-83; 8-column rays, rays.py:22-30) and the
+    endpoint feature map (show_endpoint, nerf_model.py:72-81; handler.py:248-254,270-271; model_utils.py:87-89), both produced by
+    the reference's own classes in oracle/make_goldens.py section 10."""
+    g = _load(golden_dir, "variants.npz")
+    t = lambda sd: {k: torch.from_numpy(v) for k, v in sd.items()}
+    x = torch.from_numpy(g["novd_x"])
+    for tag, D, W, seed in (("4x128", 4, 128, 2000), ("8x256", 8, 256, 2001)):
+        sd = t(nwe_amd.synthetic.make_state_dict(seed, D, W, use_view_dirs=False))
+        assert O.net_shape(sd) == (D, W, 63, 0, (4,) if D > 5 else ())
+        _close(O.mlp_forward(sd, x).numpy(), g[f"novd_y_{tag}"], 2e-5)
+    fx, fy, cx, cy = O.intrinsics(800, 800)
+    pose = torch.from_numpy(g["novd_pose"])[None]
+    rays8 = O.create_rays(pose, 800, 800, fx, fy, cx, cy, 0.1, 10.0, False)[0][torch.from_numpy(g["novd_idx"])].contiguous()
+    assert rays8.shape[1] == 8 and np.array_equal(rays8[:4].numpy(), g["novd_rays_first4"])
+    sd_c = t(nwe_amd.synthetic.thin_fog_output(nwe_amd.synthetic.make_state_dict(2001, 8, 256, use_view_dirs=False)))
+    sd_f = t(nwe_amd.synthetic.make_state_dict(2002, 8, 256, use_view_dirs=False))
+    out = O.render_rays(rays8, sd_c, sd_f, O.RenderConfig(n_samples=16, n_importance=24))
+    for k in ("rgb_fine", "depth_fine", "acc_fine", "z_std", "rgb_coarse", "depth_coarse", "acc_coarse", "z_fine"):
+        _close(out[k].numpy(), g["novd_" + k])
+    assert out["raw_fine"].shape[-1] == 5
+    # endpoint feature map
+    ge = _load(golden_dir, "embed.npz")
+    x90 = torch.cat([torch.from_numpy(ge["enc_xyz"]), torch.from_numpy(ge["enc_dir"])], -1).repeat(2, 1)
+    sd_fine = t(nwe_amd.synthetic.make_state_dict(1001, 8, 256))
+    y = O.mlp_forward(sd_fine, x90, True)
+    assert y.shape[1] == 4 + 128
+    _close(y.numpy(), g["ep_y_8x256"], 2e-5)
+    rays11 = O.create_rays(pose, 800, 800, fx, fy, cx, cy, 0.1, 10.0)[0][torch.from_numpy(g["novd_idx"])].contiguous()
+    fog = t(nwe_amd.synthetic.thin_fog(nwe_amd.synthetic.make_state_dict(1000, 8, 256)))
+    out = O.render_rays(rays11, fog, sd_fine, O.RenderConfig(n_samples=16, n_importance=24, endpoint_feat=True))
+    for k in ("rgb_fine", "depth_fine", "acc_fine", "feat_map_fine", "z_fine"):
+        _close(out[k].numpy(), g["ep_" + k])
+    assert out["feat_map_fine"].shape == (256, 128)
