@@ -1,6 +1,7 @@
 #!/bin/bash
-# Round over round on ONE box: the round-2 tree (git archive of b705984 under .ab_r2/, its own library and bench.py) against this
-# tree, alternating.  -> gpurun_out/ab_round2.txt
+# Round over round on ONE box: the round-2 tree against this tree, alternating.  -> gpurun_out/ab_round2.txt
+# Set-up (build container): mkdir .ab_r2 && git archive b705984 | tar -x -C .ab_r2 && make -C .ab_r2/nerf-workspaces-explorer_amd/csrc -j8
+# (.ab_r2/ is git-ignored; it travels to the GPU box with the snapshot: its own library, its own bench.py).
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/ab_round2.txt
 mkdir -p $ROOT/gpurun_out; : > $OUT
