@@ -493,9 +493,15 @@ __device__ __forceinline__ void tile_mma(WalkerT& wk, Frags& F, int lane, bool u
     static_assert(NKP % R == 0, "the optional segment must not shift the fragment ring");
     const float4* bp = reinterpret_cast<const float4*>(wk.bias_tab + wk.chunk * 32);
     const int h = lane >> 5;
+#ifndef NWE_SPREAD_BIAS
+#define NWE_SPREAD_BIAS 1   // the tile's four bias reads ride in the third gaps of k-steps 1..4 instead of all at its start: -0.25 % (375.5 vs 376.5 ms, alternating)
+#endif
+    constexpr bool SPREAD_BIAS = X3 && NWE_SPREAD_BIAS != 0 && (NKH + NKD) >= 6;
+    if constexpr (!SPREAD_BIAS) {
 #pragma unroll
-    for (int g = 0; g < 4; ++g) cur.bias[g] = bp[2 * g + h];
-    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+        for (int g = 0; g < 4; ++g) cur.bias[g] = bp[2 * g + h];
+        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+    }
     constexpr bool LONG_TILE = X3 && NQ >= 16;   // the (hi, lo) tiles of the last k-step live in the chunk's tail slot (Walker)
     constexpr int S_LONG_PIECES = 8;             // Shape::LONG_PIECES: a chunk of >= 8 pieces per wave is a long one
     const char* cbase = wk.cur() + lane * 16;
@@ -571,19 +577,26 @@ __device__ __forceinline__ void tile_mma(WalkerT& wk, Frags& F, int lane, bool u
         };
         if constexpr (!X3) dma();
         // fragment read of position q+PD: this chunk, or the next tile's first k-steps (visible since the barrier)
-        if (LONG_TILE && q + PD == NQ - 1) {
-            const int slot = (PHASE + q + PD) % R;   // the two reads that stay in flight across the barrier: the tail slot
-            F.lo[slot] = *reinterpret_cast<const h8*>(tbase + kTileBytes);
-            F.hi[slot] = *reinterpret_cast<const h8*>(tbase);
-        } else if (q + PD < NQ) {
-            const int slot = (PHASE + q + PD) % R;   // lo first: the first MFMA of the k-step needs hi, so one wait covers both
-            if (X3) F.lo[slot] = *reinterpret_cast<const h8*>(cbase + (2 * (q + PD) + 1) * kTileBytes);
-            F.hi[slot] = *reinterpret_cast<const h8*>(cbase + (2 * (q + PD)) * kTileBytes);
-        } else if (HASNEXT) {
-            const int slot = (PHASE + q + PD) % R;
-            if (X3) F.lo[slot] = *reinterpret_cast<const h8*>(nbase + (2 * (q + PD - NQ) + 1) * kTileBytes);
-            F.hi[slot] = *reinterpret_cast<const h8*>(nbase + (2 * (q + PD - NQ)) * kTileBytes);
-        }
+#ifndef NWE_SPLIT_READS
+#define NWE_SPLIT_READS 1   // the lo fragment is read in the k-step's THIRD gap, not beside the hi fragment: -0.45 % (362.4 vs 364.1 ms, alternating); 0 = both behind the first MFMA
+#endif
+        auto read_frag = [&](bool want_hi, bool want_lo) __attribute__((always_inline)) {
+            if (LONG_TILE && q + PD == NQ - 1) {
+                const int slot = (PHASE + q + PD) % R;   // the two reads that stay in flight across the barrier: the tail slot
+                if (want_lo) F.lo[slot] = *reinterpret_cast<const h8*>(tbase + kTileBytes);
+                if (want_hi) F.hi[slot] = *reinterpret_cast<const h8*>(tbase);
+            } else if (q + PD < NQ) {
+                const int slot = (PHASE + q + PD) % R;   // lo first: the first MFMA of the k-step needs hi, so one wait covers both
+                if (X3 && want_lo) F.lo[slot] = *reinterpret_cast<const h8*>(cbase + (2 * (q + PD) + 1) * kTileBytes);
+                if (want_hi) F.hi[slot] = *reinterpret_cast<const h8*>(cbase + (2 * (q + PD)) * kTileBytes);
+            } else if (HASNEXT) {
+                const int slot = (PHASE + q + PD) % R;
+                if (X3 && want_lo) F.lo[slot] = *reinterpret_cast<const h8*>(nbase + (2 * (q + PD - NQ) + 1) * kTileBytes);
+                if (want_hi) F.hi[slot] = *reinterpret_cast<const h8*>(nbase + (2 * (q + PD - NQ)) * kTileBytes);
+            }
+        };
+        constexpr bool SPLIT_RD = X3 && NWE_SPLIT_READS != 0;
+        read_frag(true, !SPLIT_RD);
         using Plan = EpiPlan<X3, NKH, NQ, FEEDS, DmaPlan<NB, NA, NQ>::mask()>;
         constexpr int GPK = Plan::GPK;
 #ifdef NWE_EXP_NOEPI   // timing experiment: no epilogue at all (results are garbage); the pending accumulator is kept alive
@@ -608,7 +621,7 @@ __device__ __forceinline__ void tile_mma(WalkerT& wk, Frags& F, int lane, bool u
         // order hipcc picks there costs nothing; without the fences it sinks the prefetch reads (issued PD k-steps early
         // on purpose) to their first use and clusters the epilogue into dependent chains at the end of the tile.
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        if (q + PD < NQ || HASNEXT) __builtin_amdgcn_sched_group_barrier(0x100, X3 ? 2 : 1, 0);
+        if (q + PD < NQ || HASNEXT) __builtin_amdgcn_sched_group_barrier(0x100, (X3 && !SPLIT_RD) ? 2 : 1, 0);
         if (X3) {
             __builtin_amdgcn_sched_barrier(0);
             cur.a = __builtin_amdgcn_mfma_f32_32x32x16_f16(F.lo[use], *Xh, cur.a, 0, 0, 0);
@@ -617,8 +630,12 @@ __device__ __forceinline__ void tile_mma(WalkerT& wk, Frags& F, int lane, bool u
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
             __builtin_amdgcn_sched_barrier(0);
             cur.a = __builtin_amdgcn_mfma_f32_32x32x16_f16(F.hi[use], *Xl, cur.a, 0, 0, 0);
+            if constexpr (SPLIT_RD) read_frag(false, true);
+            if constexpr (SPREAD_BIAS && q >= 1 && q <= 4) cur.bias[q - 1] = bp[2 * (q - 1) + h];
             if constexpr (NWE_EPI_ON && PEND && Plan::STAGED) epi_gap<Plan, X3, GPK * q + 2, DOT>(prev, E, inv_scale, lower, y0h, y0l, y1h, y1l, dotw, dot_ref);
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if (SPLIT_RD && (q + PD < NQ || HASNEXT)) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            if (SPREAD_BIAS && q >= 1 && q <= 4) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
     });
