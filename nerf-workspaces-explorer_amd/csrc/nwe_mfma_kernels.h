@@ -794,19 +794,35 @@ __device__ __forceinline__ void mlp_eval(WalkerT& wk, Frags& F, int lane, float 
     // layer 0: gamma(x) -> A (nothing pending in front of its first tile); the layer after it opens pair 0
     layer<S::NT, 0, S::KG, X3, false, S::N_H, true>(wk, F, lane, false, SKIP_PAIR == 0, nullptr, nullptr, Ghi, Glo, Ahi, Alo, P0, P1,
                                                     inv_scale, 0.f, 0.f);
-#pragma unroll 1
-    for (int pair = 0; pair < (FOLD ? NPAIR - 1 : NPAIR); ++pair) {
-        const bool use_g = pair == SKIP_PAIR;
-        const bool last = pair == NPAIR - 1;
+    // One pair of trunk layers.  use_g / skip_next are literals at every call site, so the run-time tests on them inside
+    // tile_mma (the optional gamma(x) k-steps, the two extra DMA pieces of a skip-layer chunk) fold away per site.
+    auto pair_body = [&](bool use_g, bool skip_next, bool last) __attribute__((always_inline)) {
         // first of pair: (gamma +) A -> B, ReLU.  Its first tile finishes the pending last tile of A (ReLU: the
         // producer is layer 0 or a non-final second-of-pair layer).
         layer<S::NT, S::KG, S::KH, X3, true, S::N_H, false>(wk, F, lane, use_g, false, Ghi, Glo, Ahi, Alo, Bhi, Blo, P0, P1, inv_scale,
                                                             0.f, 0.f);
         // second of pair: B -> A; !FOLD: the last pair's second layer is _feature_linear (no ReLU, nerf_model.py:64).
         // After it comes the next pair's first layer (skip: 2 more pieces) or the alpha tile and then the view layer.
-        layer<S::NT, 0, S::KH, X3, true, S::N_H, false>(wk, F, lane, false, !last && pair + 1 == SKIP_PAIR, nullptr, nullptr, Bhi, Blo,
+        layer<S::NT, 0, S::KH, X3, true, S::N_H, false>(wk, F, lane, false, skip_next, nullptr, nullptr, Bhi, Blo,
                                                         Ahi, Alo, P0, P1, inv_scale, 0.f, (!FOLD && last) ? -INFINITY : 0.f,
                                                         (!FOLD && last) ? S::N_V : -1);
+    };
+    constexpr int PAIRS = FOLD ? NPAIR - 1 : NPAIR;   // pairs evaluated here (FOLD: the last trunk layer stands alone below)
+#ifndef NWE_PEEL_SKIP
+#define NWE_PEEL_SKIP 1   // the pair that takes gamma(x) is peeled out of the rolled loop: no run-time use_g tests inside the tiles (6 branches per tile of every first-of-pair layer), +16 tiles of code (110 KB): -0.8 % (364.4 vs 367.2 ms, alternating); 0 = one rolled loop
+#endif
+    if constexpr (NWE_PEEL_SKIP != 0 && SKIP_PAIR >= 0 && SKIP_PAIR < PAIRS) {
+#pragma unroll 1
+        for (int pair = 0; pair < SKIP_PAIR; ++pair) pair_body(false, pair + 1 == SKIP_PAIR, false);
+        pair_body(true, false, SKIP_PAIR == NPAIR - 1);
+#pragma unroll 1
+        for (int pair = SKIP_PAIR + 1; pair < PAIRS; ++pair) pair_body(false, false, pair == NPAIR - 1);
+    } else {
+#pragma unroll 1
+        for (int pair = 0; pair < PAIRS; ++pair) {
+            const bool last = pair == NPAIR - 1;
+            pair_body(pair == SKIP_PAIR, !last && pair + 1 == SKIP_PAIR, last);
+        }
     }
     float sig = 0.f;   // FOLD: this lane half's share of _alpha_linear . h
     if constexpr (FOLD) {
