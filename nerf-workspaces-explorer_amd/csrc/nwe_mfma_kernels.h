@@ -554,6 +554,10 @@ __device__ __forceinline__ void tile_mma(WalkerT& wk, Frags& F, int lane, bool u
         }
         // first MFMA of the k-step (hi.hi); everything else of the k-step is issued behind it, while it executes
         const int use = (PHASE + q) % R;
+#ifndef NWE_ONE_WAIT
+#define NWE_ONE_WAIT 1   // both fragments of the k-step are "used" in front of its first MFMA, so hipcc waits for them once (lgkmcnt)
+#endif                   // instead of once per MFMA that consumes one: 16 fewer s_waitcnt per long tile, -0.35 % (372.2 vs 373.5 ms); 0 = off
+        if constexpr (X3 && NWE_ONE_WAIT != 0) asm volatile("" :: "v"(F.hi[use]), "v"(F.lo[use]));
         if (q == 0 && !(NKP > 0 && pre_done)) {
             f16v zero;
 #pragma unroll

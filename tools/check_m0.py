@@ -1,8 +1,11 @@
 """The MFMA render kernels keep the LDS-DMA destination in M0 across statements (one write per group of pieces), which is
 sound only while hipcc emits no M0 use of its own in those kernels: disassemble the built library and check that every
 instruction touching m0 in a render_mfma_kernel is one of ours - `s_mov_b32 m0, <scalar register>` immediately followed by
-`s_nop 0` and the `global_load_lds_dwordx4` it addresses, the one asm statement of Walker::piece - and that no instruction
-with an IMPLICIT M0 operand (s_set_gpr_idx_*, movrel, GWS/GDS, sendmsg, buffer loads with lds, ...) appears at all.
+`s_nop 0` and the `global_load_lds_dwordx4` it addresses, the one asm statement of Walker::piece (a write one gap ahead of its
+piece, a form round 3 tried and dropped, is recognised too) - that no instruction with an IMPLICIT M0 operand
+(s_set_gpr_idx_*, movrel, GWS/GDS, sendmsg, buffer loads with lds, ...) appears at all, and that along straight-line code the
+pieces between two M0 writes sit at consecutive 1-KiB instruction offsets (a piece at the wrong offset writes another piece's
+tile or past the LDS allocation).
 
 Run by `__graft_entry__.build()` (a build that breaks the invariant fails) and by tests/test_abi.py."""
 import os
@@ -36,10 +39,41 @@ def check(lib_path: str) -> int:
                 continue
             dis = subprocess.run([OBJDUMP, "-d", name], cwd=tmp, check=True, capture_output=True, text=True).stdout
             in_kernel = False
+            x3 = False          # the three-product instantiation (4th template argument)
             body = []           # instructions of the current render_mfma_kernel, in order
+            addrs = []          # their byte addresses (from objdump's trailing comment), or None
 
             def close():
-                nonlocal checked, pieces
+                nonlocal checked, pieces, x3
+                unknown = True
+                # Pieces of a group ride on the instruction offset: between two M0 writes the offsets of consecutive pieces go up
+                # in steps of 1 KiB (a piece issued at the wrong offset - round 3 shipped one for an hour: a group's first piece
+                # without its `case 0` - writes another piece's tile, or past the LDS allocation)
+                last_off = None
+                targets = set()
+                for ins, addr in zip(body, addrs):   # join points: the continuity rule holds along straight-line code only
+                    mb = re.match(r"s_c?branch\w*\s+(\d+)$", ins)
+                    if mb and addr is not None:
+                        rel = int(mb.group(1))
+                        rel = rel - 65536 if rel >= 32768 else rel
+                        targets.add(addr + 4 + 4 * rel)
+                for ins, addr in (zip(body, addrs) if x3 else []):     # the single-pass kernels skip the lo pieces (every second one) on purpose
+                    if addr in targets or ins.startswith(("s_cbranch", "s_branch")):
+                        last_off = None
+                        unknown = True      # a piece behind a join may continue a group opened on either path
+                        continue
+                    if re.search(r"\bm0\b", ins):
+                        last_off = None
+                        unknown = False
+                    elif ins.startswith("global_load_lds_dwordx4"):
+                        mo = re.search(r"offset:(\d+)", ins)
+                        off = int(mo.group(1)) if mo else 0
+                        if last_off is not None and off != last_off + 1024:
+                            raise AssertionError(f"LDS-DMA piece at offset {off} behind one at {last_off} with no M0 write in between")
+                        if last_off is None and not unknown and off not in (0, 2048, 3072):
+                            raise AssertionError(f"first piece behind an M0 write at offset {off} (a group starts at 0, a tail at 2048 or 3072)")
+                        last_off = off
+                        unknown = False
                 for i, ins in enumerate(body):
                     if implicit.match(ins):
                         raise AssertionError(f"instruction with an implicit M0 operand in the MFMA kernel: {ins!r}")
@@ -48,25 +82,42 @@ def check(lib_path: str) -> int:
                     if re.search(r"\bm0\b", ins):
                         if not re.fullmatch(r"s_mov_b32 m0, (s\d+|vcc_lo|vcc_hi)", ins):
                             raise AssertionError(f"unexpected M0 use in the MFMA kernel: {ins!r}")
-                        # ours come as ONE asm statement: the write, one wait state, the piece it addresses (Walker::piece);
-                        # a compiler-emitted write of the same spelling would not be followed by exactly that
+                        # ours come either as ONE asm statement - the write, one wait state, the piece it addresses (Walker::piece)
+                        # - or, inside the tiles, one MFMA gap ahead of the piece (Walker::piece_m0): then the next M0-relevant
+                        # instruction must be that piece, at least one instruction (the wait state) and at most one gap's worth
+                        # of instructions later, with no other M0 write in between
                         nxt = body[i + 1:i + 3]
-                        if len(nxt) < 2 or nxt[0] != "s_nop 0" or not nxt[1].startswith("global_load_lds_dwordx4"):
-                            raise AssertionError(f"M0 write not followed by `s_nop 0` + LDS-DMA piece (not one of ours?): {[ins] + nxt!r}")
+                        if len(nxt) == 2 and nxt[0] == "s_nop 0" and nxt[1].startswith("global_load_lds_dwordx4"):
+                            checked += 1
+                            continue
+                        for j in range(i + 1, min(i + 40, len(body))):
+                            if re.search(r"\bm0\b", body[j]):
+                                raise AssertionError(f"second M0 write before the piece of the first: {ins!r} ... {body[j]!r}")
+                            if body[j].startswith("global_load_lds_dwordx4"):
+                                if j < i + 2:
+                                    raise AssertionError(f"no wait state between an M0 write and its LDS-DMA piece: {body[i:j + 1]!r}")
+                                break
+                        else:
+                            raise AssertionError(f"M0 write without an LDS-DMA piece within a gap's distance (not one of ours?): {ins!r}")
                         checked += 1
                 body.clear()
+                addrs.clear()
 
             for line in dis.splitlines():
                 m = re.match(r"^[0-9a-f]+ <(\S+)>:", line)
                 if m:
                     close()
                     in_kernel = "render_mfma_kernel" in m.group(1)
+                    mx = re.search(r"render_mfma_kernelILi\d+ELi\d+ELi(?:n?\d+)ELb([01])", m.group(1))
+                    x3 = bool(mx and mx.group(1) == "1")
                     continue
                 if not in_kernel:
                     continue
                 ins = line.split("//")[0].strip()
                 if ins:
                     body.append(ins)
+                    ma = re.search(r"//\s*([0-9A-Fa-f]+):", line)
+                    addrs.append(int(ma.group(1), 16) if ma else None)
             close()
         if checked > pieces:
             raise AssertionError(f"{checked} M0 writes but only {pieces} LDS-DMA pieces")
