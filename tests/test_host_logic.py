@@ -228,3 +228,36 @@ def test_kernel_sum_order_is_torch_sum():
         seq = (seq + w[:, i].numpy()).astype(np.float32)
     assert all(_torch_sum_order(row) == s for row, s in zip(w.numpy(), want))
     assert (seq != want).mean() > 0.5        # the naive order is NOT torch's on most rays: the reason this exists
+
+
+def test_m0_checker_rules():
+    """tools/check_m0.py on hand-made instruction lists: the product's form passes; a compiler-looking M0 write, an implicit M0
+    user, a piece at the wrong instruction offset (the bug an experiment of round 3 built) and a group that does not start at
+    offset 0 are refused; branches and branch targets reset the straight-line rule."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import check_m0
+    P = lambda off=0: "global_load_lds_dwordx4 v1, s[2:3]" + (f" offset:{off}" if off else "")
+    W = ["s_mov_b32 m0, s7", "s_nop 0"]
+    M = "v_mfma_f32_32x32x16_f16 v[0:15], v[16:19], a[0:3], v[0:15]"
+    good = W + [P(), M, P(1024), M, P(2048), M, P(3072), M] + W + [P(), M, P(1024)] + W + [P(2048), M, P(3072)]
+    assert check_m0.analyse(good) == (3, 8)
+    bad_cases = {
+        "not one of ours": ["s_mov_b32 m0, s7", M, P()],
+        "unexpected M0 use": ["s_mov_b32 m0, 0x1000", "s_nop 0", P()],
+        "implicit M0": W + [P(), "s_set_gpr_idx_on s3, gpr_idx(SRC0)"],
+        "behind one at 3072": W + [P(3072), M, P(1024)],                 # a group's first piece issued at the wrong offset
+        "behind one at 0": W + [P(), M, P(2048)],                        # a piece skipped
+        "first piece behind an M0 write at offset 1024": W + [P(1024)],
+    }
+    for what, body in bad_cases.items():
+        with pytest.raises(AssertionError, match=what):
+            check_m0.analyse(body)
+    # the single-pass kernels stream every second piece: no continuity rule for them
+    assert check_m0.analyse(W + [P(), M, P(2048)], x3=False) == (1, 2)
+    # a branch, or the target of one, ends straight-line reasoning: the piece behind it may continue either path's group
+    body = W + [P(), "s_cbranch_vccnz 2", P(1024), P(2048), M, P(3072)]
+    addrs = [0, 4, 8, 16, 20, 28, 36, 44]                                # the branch at 16 targets 16 + 4 + 8 = 28: P(2048)
+    assert check_m0.analyse(body, addrs) == (1, 4)
+    with pytest.raises(AssertionError):
+        check_m0.analyse(W + [P(), P(1024), M, P(3072)], [0, 4, 8, 16, 24, 32])
