@@ -206,9 +206,13 @@ def main() -> None:
     poses = np.stack([sweep_pose(k, frames_per_step) for k in range(frames_per_step)])
     kernel_ms = []
 
+    parts = []                                            # per step: [(ms, rays)] of the launches the frame took
+
     def step():
         out = tsr.render_frames(poses, H, W)
         kernel_ms.append(h.renderer.last_kernel_ms())     # blocks until the launch has finished (HIP events on its stream)
+        if args.precision != "f32":
+            parts.append(h.renderer.last_launch_parts())
         return out
 
     def fence():
@@ -221,6 +225,7 @@ def main() -> None:
     for _ in range(args.warmup):
         step()
     kernel_ms.clear()
+    parts.clear()
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -300,6 +305,18 @@ def main() -> None:
         mfma_per_eval = [r0.packed_stream(w).size // 2048 for w in (0, 1)]
         executed = (H * W * frames_per_step // world) / 32 * (NS * mfma_per_eval[0] + (NS + NI) * mfma_per_eval[1]) * passes * 32768
         exec_tflops = executed / (k_ms * 1e-3) / 1e12 if args.precision != "f32" else None
+        # the launches of a frame, timed apart by the library (an event between them): under the hybrid plan the DOMINANT kernel
+        # is the packets instantiation over the full rounds of workgroups, the sample-split instantiation renders the rest
+        launches = None
+        if parts:
+            flops_per_ray = NS * r0.flops_per_eval(0) + (NS + NI) * r0.flops_per_eval(1)
+            launches = []
+            for i, what in enumerate(("packets (SPLIT = false): the dominant kernel", "sample split (SPLIT = true): the ragged last round")[:len(parts[0])]):
+                ms_i = float(np.mean([p[i][0] for p in parts]))
+                rays_i = parts[0][i][1]
+                launches.append({"instantiation": what if len(parts[0]) == 2 else "one launch", "rays": rays_i, "kernel_ms": ms_i,
+                                 "algorithmic_tflops": rays_i * flops_per_ray / (ms_i * 1e-3) / 1e12,
+                                 "frac": rays_i * flops_per_ray / (ms_i * 1e-3) / 1e12 / PEAK_F16_TFLOPS})
         traffic, traffic_note = profiled_traffic() if (world == 1 and args.precision == "f16x3" and not args.unfolded) else (None, "not profiled for this mode")
         line = {
             "metric": "ray-samples/sec (800x800, 192 samples, 8x256 MLP)", "value": value, "unit": "ray-samples/s",
@@ -319,6 +336,7 @@ def main() -> None:
                          "traffic": traffic, "traffic_note": traffic_note + "; algorithmic 1.76e7 B per launch (poses in, weights once, rgb/depth/acc out)",
                          "kernel": ("render_mfma_kernel<256,8,4,%s>" % ("unfolded" if args.unfolded else "folded")) if args.precision != "f32" else "render_f32_kernel",
                          "launch_plan": r0.debug_last_plan(),
+                         "launches": launches,
                          "launch_plan_note": "0 = one launch of 4-packet workgroups; 2 = the full rounds of workgroups as packets + the ragged last "
                                              "round sample-split in a second launch of the same kernel template right behind it; kernel_ms covers both",
                          "kernel_ms": k_ms, "algorithmic_flops_per_launch": flops_per_launch,

@@ -178,6 +178,12 @@ int64_t nwe_flops_per_eval(const nwe_ctx *ctx, int which);
  * thread's current HIP device as it found it. */
 float nwe_last_kernel_ms(nwe_ctx *ctx);
 
+/* The same launch taken apart: a frame whose last round of workgroups is ragged is rendered as TWO launches of the kernel
+ * template back to back (the full rounds as four-packet workgroups, the rest sample-split; nwe_debug_last_plan == 2).
+ * ms2[0], rays2[0]: the first (or only) launch; ms2[1], rays2[1]: the second, -1 / 0 if there was none.  Blocks like
+ * nwe_last_kernel_ms. */
+int nwe_last_launch_parts(nwe_ctx *ctx, float *ms2, int64_t *rays2);
+
 /* --- test hooks ------------------------------------------------------------------------------- */
 
 /* Size in bytes / host copy of the MFMA weight stream packed for network `which` (0 if that network

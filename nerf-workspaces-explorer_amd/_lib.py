@@ -21,7 +21,7 @@ SYMBOLS = ("nwe_create", "nwe_destroy", "nwe_last_error", "nwe_set_network", "nw
            "nwe_create_rays", "nwe_render_rays", "nwe_to8b", "nwe_flops_per_eval", "nwe_last_kernel_ms", "nwe_packed_bytes",
            "nwe_packed_copy", "nwe_packed_bias_count", "nwe_packed_bias_copy", "nwe_packed_scale",
            "nwe_debug_set_fine_depths", "nwe_debug_set_raw", "nwe_debug_set_coarse_weights", "nwe_debug_set_fold", "nwe_set_train_tables", "nwe_set_white_background", "nwe_debug_set_decomposition", "nwe_debug_last_plan", "nwe_debug_set_stamps", "nwe_selftest",
-           "nwe_last_warning", "nwe_debug_peer_access", "nwe_set_network_no_view_dirs")
+           "nwe_last_warning", "nwe_debug_peer_access", "nwe_set_network_no_view_dirs", "nwe_last_launch_parts")
 
 
 class Outputs(C.Structure):
@@ -61,6 +61,7 @@ def load() -> C.CDLL:
         "nwe_to8b": (I, [P, P, P, I64, P]),
         "nwe_flops_per_eval": (I64, [P, I]),
         "nwe_last_kernel_ms": (F, [P]),
+        "nwe_last_launch_parts": (I, [P, C.POINTER(F), C.POINTER(I64)]),
         "nwe_packed_bytes": (I64, [P, I]),
         "nwe_packed_copy": (I, [P, I, P, I64]),
         "nwe_packed_bias_count": (I64, [P, I]),

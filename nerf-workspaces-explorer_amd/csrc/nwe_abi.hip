@@ -47,8 +47,10 @@ struct nwe_ctx {
     struct Slot {
         float* d_poses = nullptr;
         int poses_cap = 0;
-        hipEvent_t ev0 = nullptr, ev1 = nullptr;
+        hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_mid = nullptr;   // ev_mid: between the two launches of the hybrid plan
         bool used = false;
+        bool has_mid = false;
+        int64_t rays_first = 0, rays_total = 0;
     };
     static constexpr int kSlots = 4;
     Slot slots[kSlots];
@@ -307,6 +309,7 @@ int acquire_slot(nwe_ctx* c, nwe_ctx::Slot** out, bool render = true) {
     if (!s.ev0) {
         HIPCHK(c, hipEventCreate(&s.ev0));
         HIPCHK(c, hipEventCreate(&s.ev1));
+        HIPCHK(c, hipEventCreate(&s.ev_mid));
     }
     if (s.used) HIPCHK(c, hipEventSynchronize(s.ev1));
     if (render) c->last_slot = c->next_slot;
@@ -365,12 +368,17 @@ int launch(nwe_ctx* ctx, nwe_ctx::Slot& slot, RenderArgs& a, int precision, void
     a.stamps = ctx->stamps;   // only read by -DNWE_STAMPS builds of the kernel (nwe_debug_set_stamps)
     if (a.n_rays <= 0) return NWE_OK;
     HIPCHK(ctx, hipEventRecord(slot.ev0, stream));
+    slot.has_mid = false; slot.rays_first = slot.rays_total = a.n_rays;
     if (precision == NWE_PREC_F32) {
         launch_render_f32(a, ctx->net[0].f32, ctx->net[ctx->ni > 0 ? 1 : 0].f32, stream);
     } else {
+        LaunchInfo info;
+        info.mid = slot.ev_mid;
         if (!launch_render_mfma(a, ctx->net[0].mf, ctx->net[ctx->ni > 0 ? 1 : 0].mf, precision == NWE_PREC_F16X3, ctx->decomposition, stream,
-                                &ctx->last_plan))
+                                &info))
             return fail(ctx, NWE_ERR_UNSUPPORTED, "coarse and fine networks must have the same shape for the MFMA kernel");
+        ctx->last_plan = info.plan;
+        slot.has_mid = info.mid_recorded; slot.rays_first = info.rays_first;
     }
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipEventRecord(slot.ev1, stream));
@@ -418,6 +426,7 @@ void nwe_destroy(nwe_ctx* c) {
             if (sl.d_poses) (void)hipFree(sl.d_poses);
             if (sl.ev0) (void)hipEventDestroy(sl.ev0);
             if (sl.ev1) (void)hipEventDestroy(sl.ev1);
+            if (sl.ev_mid) (void)hipEventDestroy(sl.ev_mid);
         }
     }
     delete c;
@@ -724,6 +733,24 @@ float nwe_last_kernel_ms(nwe_ctx* c) {
     if (e == hipSuccess) e = hipEventElapsedTime(&ms, s.ev0, s.ev1);
     if (e != hipSuccess) { c->err = std::string("nwe_last_kernel_ms: ") + hipGetErrorString(e); (void)hipGetLastError(); return -1.f; }
     return ms;
+}
+
+int nwe_last_launch_parts(nwe_ctx* c, float* ms2, int64_t* rays2) {
+    if (!c || !ms2 || !rays2) return NWE_ERR_INVALID;
+    ms2[0] = ms2[1] = -1.f; rays2[0] = rays2[1] = 0;
+    if (c->host_only || c->last_slot < 0 || !c->slots[c->last_slot].used) return fail(c, NWE_ERR_STATE, "nothing has been launched");
+    const nwe_ctx::Slot& s = c->slots[c->last_slot];
+    DeviceGuard guard;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipEventSynchronize(s.ev1));
+    rays2[0] = s.rays_first; rays2[1] = s.rays_total - s.rays_first;
+    if (s.has_mid) {
+        HIPCHK(c, hipEventElapsedTime(&ms2[0], s.ev0, s.ev_mid));
+        HIPCHK(c, hipEventElapsedTime(&ms2[1], s.ev_mid, s.ev1));
+    } else {
+        HIPCHK(c, hipEventElapsedTime(&ms2[0], s.ev0, s.ev1));
+    }
+    return NWE_OK;
 }
 
 int64_t nwe_packed_bytes(const nwe_ctx* c, int which) {

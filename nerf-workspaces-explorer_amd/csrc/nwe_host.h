@@ -40,9 +40,16 @@ bool mfma_supported(int D, int W, int in_xyz, int in_dir, int skip, bool folded)
 // returns false if the shape has no instantiation.  decomposition: -1 = pick by frame size, 0 = four ray packets per
 // workgroup, 1 = one packet per workgroup with its samples dealt to the four waves, 2 = full rounds as 0 and the ragged
 // last round as 1 in a second launch (bit-identical results)
-// *plan_out (may be null) receives the plan taken (0 / 1 / 2 as above)
+// *info (may be null): in, `mid` = an event to record between the two launches of plan 2 (or null); out, the plan taken
+// (0 / 1 / 2 as above) and the rays the first launch got (all of them unless plan 2)
+struct LaunchInfo {
+    hipEvent_t mid = nullptr;
+    int plan = -1;
+    int64_t rays_first = 0;
+    bool mid_recorded = false;
+};
 bool launch_render_mfma(const RenderArgs& a, const NetMfma& nc, const NetMfma& nf, bool three_pass, int decomposition, hipStream_t stream,
-                        int* plan_out);
+                        LaunchInfo* info);
 
 constexpr int kTileBytes = 1024;
 int mfma_max_samples();      // n_samples the MFMA kernel's per-wave LDS buffers are sized for

@@ -21,7 +21,7 @@ bool mfma_supported(int D, int W, int in_xyz, int in_dir, int skip, bool folded)
 int mfma_max_samples() { return kSplitMaxSamples; }
 
 #define NWE_EXTERN_SHAPE(W_, D_, SKIP_, FOLD_) \
-    extern template bool launch_t<W_, D_, SKIP_, FOLD_>(const RenderArgs&, const NetMfma&, const NetMfma&, bool, int, hipStream_t, int*)
+    extern template bool launch_t<W_, D_, SKIP_, FOLD_>(const RenderArgs&, const NetMfma&, const NetMfma&, bool, int, hipStream_t, LaunchInfo*)
 NWE_EXTERN_SHAPE(256, 8, 4, true);
 #ifndef NWE_ONLY_HEADLINE
 NWE_EXTERN_SHAPE(256, 8, 4, false);
@@ -35,24 +35,24 @@ NWE_EXTERN_SHAPE(128, 4, -1, false);
 #undef NWE_EXTERN_SHAPE
 
 bool launch_render_mfma(const RenderArgs& a, const NetMfma& nc, const NetMfma& nf, bool three_pass, int decomposition, hipStream_t stream,
-                        int* plan_out) {
+                        LaunchInfo* info) {
     if (a.n_importance > 0 && (nf.D != nc.D || nf.W != nc.W || nf.skip != nc.skip || nf.folded != nc.folded)) return false;
     if (a.n_samples > kSplitMaxSamples) return false;
     const int D = nc.D, W = nc.W, skip = nc.skip;
     if (nc.folded) {
-        if (D == 8 && W == 256 && skip == 4) return launch_t<256, 8, 4, true>(a, nc, nf, three_pass, decomposition, stream, plan_out);
+        if (D == 8 && W == 256 && skip == 4) return launch_t<256, 8, 4, true>(a, nc, nf, three_pass, decomposition, stream, info);
 #ifndef NWE_ONLY_HEADLINE
-        if (D == 4 && W == 128 && skip == -1) return launch_t<128, 4, -1, true>(a, nc, nf, three_pass, decomposition, stream, plan_out);
-        if (D == 8 && W == 128 && skip == 4) return launch_t<128, 8, 4, true>(a, nc, nf, three_pass, decomposition, stream, plan_out);
-        if (D == 4 && W == 256 && skip == -1) return launch_t<256, 4, -1, true>(a, nc, nf, three_pass, decomposition, stream, plan_out);
-        if (D == 6 && W == 256 && skip == 4) return launch_t<256, 6, 4, true>(a, nc, nf, three_pass, decomposition, stream, plan_out);
-        if (D == 6 && W == 128 && skip == 4) return launch_t<128, 6, 4, true>(a, nc, nf, three_pass, decomposition, stream, plan_out);
+        if (D == 4 && W == 128 && skip == -1) return launch_t<128, 4, -1, true>(a, nc, nf, three_pass, decomposition, stream, info);
+        if (D == 8 && W == 128 && skip == 4) return launch_t<128, 8, 4, true>(a, nc, nf, three_pass, decomposition, stream, info);
+        if (D == 4 && W == 256 && skip == -1) return launch_t<256, 4, -1, true>(a, nc, nf, three_pass, decomposition, stream, info);
+        if (D == 6 && W == 256 && skip == 4) return launch_t<256, 6, 4, true>(a, nc, nf, three_pass, decomposition, stream, info);
+        if (D == 6 && W == 128 && skip == 4) return launch_t<128, 6, 4, true>(a, nc, nf, three_pass, decomposition, stream, info);
 #endif
         return false;
     }
 #ifndef NWE_ONLY_HEADLINE
-    if (D == 8 && W == 256 && skip == 4) return launch_t<256, 8, 4, false>(a, nc, nf, three_pass, decomposition, stream, plan_out);
-    if (D == 4 && W == 128 && skip == -1) return launch_t<128, 4, -1, false>(a, nc, nf, three_pass, decomposition, stream, plan_out);
+    if (D == 8 && W == 256 && skip == 4) return launch_t<256, 8, 4, false>(a, nc, nf, three_pass, decomposition, stream, info);
+    if (D == 4 && W == 128 && skip == -1) return launch_t<128, 4, -1, false>(a, nc, nf, three_pass, decomposition, stream, info);
 #endif
     return false;
 }

@@ -1272,7 +1272,7 @@ inline void launch_one(RenderArgs a, const NetMfma& nc, const NetMfma& nf, bool 
 
 template <int W, int D, int SKIP, bool FOLD>
 bool launch_t(const RenderArgs& a, const NetMfma& nc, const NetMfma& nf, bool three_pass, int decomposition, hipStream_t stream,
-                     int* plan_out) {
+                     LaunchInfo* info) {
     using S = Shape<W, D>;
     constexpr int NCH = FOLD ? S::N_CHUNKS_FOLDED : S::N_CHUNKS;
     if (nc.n_chunks != NCH || (a.n_importance > 0 && nf.n_chunks != NCH)) return false;   // the kernel copies NCH bias rows
@@ -1296,9 +1296,10 @@ bool launch_t(const RenderArgs& a, const NetMfma& nc, const NetMfma& nf, bool th
     int plan = t_hybrid < 0.992 * t_single ? 2 : (t_packet <= t_split ? 0 : 1);
     if (decomposition >= 0) plan = decomposition;   // nwe_debug_set_decomposition: tests force one
     if (a.n_samples > kPacketMaxSamples) plan = 1;  // only the single-packet workgroup has LDS for that many coarse weights
-    if (plan_out) *plan_out = plan;
+    if (info) { info->plan = plan; info->rays_first = plan == 2 ? full : a.n_rays; info->mid_recorded = false; }
     if (plan == 2) {
         launch_one<W, D, SKIP, FOLD>(a, nc, nf, three_pass, false, 0, full, stream);
+        if (info && info->mid) info->mid_recorded = hipEventRecord(info->mid, stream) == hipSuccess;   // the two launches timed apart
         launch_one<W, D, SKIP, FOLD>(a, nc, nf, three_pass, true, full, a.n_rays - full, stream);
     } else {
         launch_one<W, D, SKIP, FOLD>(a, nc, nf, three_pass, plan == 1, 0, a.n_rays, stream);

@@ -290,6 +290,13 @@ class Renderer:
     def last_kernel_ms(self) -> float:
         return float(self._lib.nwe_last_kernel_ms(self._ctx))
 
+    def last_launch_parts(self):
+        """[(ms, rays), ...] of the launches the last render took: one, or - under the hybrid plan - the packets launch over
+        the full rounds of workgroups and the sample-split launch over the ragged rest."""
+        ms, rays = (C.c_float * 2)(), (C.c_int64 * 2)()
+        self._check(self._lib.nwe_last_launch_parts(self._ctx, ms, rays), "nwe_last_launch_parts")
+        return [(float(ms[i]), int(rays[i])) for i in range(2) if ms[i] >= 0]
+
     def mfma_supported(self, which: int) -> bool:
         """True if network `which` has been packed for the MFMA kernel (its shape has an instantiation)."""
         return int(self._lib.nwe_packed_bytes(self._ctx, which)) > 0

@@ -54,6 +54,11 @@ int main(void) {
     CHECK(nwe_render_tiled(NULL, 0, NULL, 0, 0, 0, 1, 1, 0, 0, 0.1f, 10.f, 0, NULL, NULL, NULL, NULL, NULL) == NWE_ERR_INVALID);
     CHECK(nwe_debug_last_plan(ctx) == -1 && nwe_last_kernel_ms(ctx) < 0.f);
     CHECK(strlen(nwe_last_warning(ctx)) == 0 && nwe_debug_peer_access(ctx, ctx) == -1);   /* host-only contexts have no device */
+    {
+        float ms2[2]; int64_t rays2[2];
+        CHECK(nwe_last_launch_parts(ctx, ms2, rays2) == NWE_ERR_STATE && ms2[0] < 0.f && rays2[0] == 0);
+        CHECK(nwe_last_launch_parts(ctx, NULL, rays2) == NWE_ERR_INVALID);
+    }
     /* the packed stream and bias table come back whole (and the copies refuse a wrong size) */
     {
         const int64_t nb = nwe_packed_bytes(ctx, NWE_NET_FINE), nbias = nwe_packed_bias_count(ctx, NWE_NET_FINE);
@@ -69,7 +74,8 @@ int main(void) {
     fn refs[] = {(fn)nwe_render, (fn)nwe_create_rays, (fn)nwe_to8b, (fn)nwe_packed_copy, (fn)nwe_packed_bias_copy,
                  (fn)nwe_debug_set_fine_depths, (fn)nwe_debug_set_raw, (fn)nwe_debug_set_coarse_weights, (fn)nwe_set_white_background,
                  (fn)nwe_set_train_tables, (fn)nwe_debug_set_decomposition, (fn)nwe_debug_set_stamps, (fn)nwe_selftest,
-                 (fn)nwe_last_warning, (fn)nwe_debug_peer_access};
+                 (fn)nwe_last_warning, (fn)nwe_debug_peer_access,
+                 (fn)nwe_set_network_no_view_dirs, (fn)nwe_last_launch_parts};
     for (unsigned i = 0; i < sizeof refs / sizeof refs[0]; ++i) CHECK(refs[i] != (fn)0);
     nwe_destroy(ctx);
     for (int l = 0; l < D + 4; ++l) { free(w[l]); free(b[l]); }

@@ -942,6 +942,10 @@ def test_c4_full_size_row_tiles_equal_the_frame(r_c3):
         assert r_c3.debug_last_plan() == 2      # 80 000 rays = 2.4 rounds of packets: two full rounds as packets, the rest sample-split
     for k in ("rgb", "depth", "acc"):
         assert torch.equal(torch.cat([t[k] for t in tiles]), whole[k]), k
+    # the launches of the last tile, timed apart: two rounds of packets + 14 464 rays sample-split, adding up to the whole
+    lp = r_c3.last_launch_parts()
+    assert cus != 256 or (len(lp) == 2 and lp[0][1] == 2 * 256 * 128 and lp[0][1] + lp[1][1] == 80000)
+    assert all(ms_ > 0 for ms_, _ in lp) and abs(sum(ms_ for ms_, _ in lp) - r_c3.last_kernel_ms()) < 0.05 * r_c3.last_kernel_ms()
     print(f"C4 on one GPU: whole frame {t_whole:.1f} ms; the 8 row tiles {', '.join(f'{m:.1f}' for m in ms)} ms "
           f"(sum {sum(ms):.1f}, slowest {max(ms):.1f} = the frame latency on 8 GPUs before the gather)")
     assert int(whole["flags"].item()) & 0x7 == 0          # rgb, depth, acc finite (disp = 1/(depth/acc) may be NaN where acc = 0, like the reference)
