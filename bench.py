@@ -513,6 +513,30 @@ def other_configs(args):
             del hd, out
         except Exception as exc:   # noqa: BLE001 - reported, the headline stands
             res[key] = {"workload": what, "error": f"{type(exc).__name__}: {exc}"}
+    # the C3 frame with networks that take no view directions (rendering.use_view_dirs: False, nerf_model.py:42-43,78-79):
+    # the MFMA kernel's own instantiation - trunk + one tile of _output_linear - through the ctypes wrapper directly (the
+    # handler would read the flag from its YAML)
+    key, what = "C3_no_view_dirs", "800x800, 64+128, 8x256 trunk + _output_linear (use_view_dirs: False)"
+    progress(f"config {key}: {what}")
+    try:
+        from nwe_amd.handler import pinhole_intrinsics
+        r = nwe_amd.Renderer(0)
+        r.set_network(0, nwe_amd.synthetic.make_state_dict(1000, 8, 256, use_view_dirs=False))
+        r.set_network(1, nwe_amd.synthetic.make_state_dict(1001, 8, 256, use_view_dirs=False))
+        r.set_sampling(64, 128)
+        fx, fy, cx, cy = pinhole_intrinsics(800, 800)
+        ms = []
+        for _ in range(3):
+            out = r.render(sweep_pose(0, 1), 800, 800, fx=fx, fy=fy, cx=cx, cy=cy, near=0.1, far=10.0, precision=args.precision)
+            ms.append(r.last_kernel_ms())
+        k = min(ms[1:])
+        flops = 640000 * (64 * r.flops_per_eval(0) + 192 * r.flops_per_eval(1))
+        res[key] = {"workload": what, "kernel_ms": k, "rays": 640000, "ray_samples_per_s": 640000 * 192 / k * 1e3,
+                    "mlp_evals_per_s": 640000 * 256 / k * 1e3, "algorithmic_tflops": flops / k / 1e9,
+                    "frac_of_dense_f16_peak": flops / k / 1e9 / PEAK_F16_TFLOPS, "plan": r.debug_last_plan(), "flags": int(out["flags"].item())}
+        r.close()
+    except Exception as exc:   # noqa: BLE001
+        res[key] = {"workload": what, "error": f"{type(exc).__name__}: {exc}"}
     return res
 
 

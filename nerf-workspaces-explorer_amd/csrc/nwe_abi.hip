@@ -21,7 +21,7 @@ struct NetState {
     NetF32 f32 = {};
     float* d_blob = nullptr;
     bool mfma_ok = false;
-    bool folded = false;           // MFMA stream: _feature_linear multiplied into the view layer
+    int form = kFormFolded;        // MFMA stream: which formulation it holds (nwe_host.h: Form)
     std::vector<uint8_t> stream;   // MFMA kernel: 1-KiB tiles in consumption order
     std::vector<float> bias_tab;   // MFMA kernel: 32 floats per chunk, then (folded) the dot rows of _alpha_linear
     int n_chunks = 0;              // chunks of the stream = bias rows in front of the dot rows
@@ -170,17 +170,22 @@ void put_chunk(NetState& n, const T* w, const T* b, int ld, const RowMap& rows, 
 
 // Stream order = the order mlp_eval() consumes chunks in.
 //
-// n.folded: _feature_linear has no activation (nerf/models/nerf_model.py:64) and its output feeds only the view layer
+// kFormFolded: _feature_linear has no activation (nerf/models/nerf_model.py:64) and its output feeds only the view layer
 // (:66-70), so  W_v [W_f h + b_f ; gamma(d)] + b_v = (W_v[:, :W] W_f) h + W_v[:, W:] gamma(d) + (b_v + W_v[:, :W] b_f):
 // the product is formed here in fp64 and split into (hi, lo) directly from the double, the feature layer's chunks
 // disappear from the stream (8 of 78 chunks, 11 % of the MFMAs of an 8x256 evaluation).
+//
+// kFormNoViewDirs (use_view_dirs=False): layer D is _output_linear [out_ch, W]; its rows 0..3 (rgb_raw, sigma_raw) form the one
+// chunk behind the trunk, duplicated into tile rows 4..7 for the upper lane half; further channels are ignored as the
+// reference ignores them (model_utils.py:62,71).
 void pack_mfma(NetState& n, const float* const* w, const float* const* b) {
     const int D = n.D, W = n.W, KH = W / 16;
     const int iv = D, ife = D + 1, ia = D + 2, irgb = D + 3;
+    const bool folded = n.form == kFormFolded, noview = n.form == kFormNoViewDirs;
     n.stream.clear();
     n.bias_tab.clear();
     std::vector<double> wv, bv;   // folded view layer [W/2, W + in_dir] and its bias
-    if (n.folded) {
+    if (folded) {
         const int ldv = W + n.in_dir;
         wv.assign((size_t)(W / 2) * ldv, 0.0);
         bv.assign(W / 2, 0.0);
@@ -203,10 +208,10 @@ void pack_mfma(NetState& n, const float* const* w, const float* const* b) {
     // accumulator by 1/scale before adding the bias; both scalings are exact.
     const int in_dims[4] = {W + n.in_dir, W, W, W / 2}, out_dims[4] = {W / 2, W, 1, 3};
     double wmax = 0.0;
-    for (int li = 0; li < D + 4; ++li) {
-        if (n.folded && (li == iv || li == ife || li == ia)) continue;   // folded: multiplied out / evaluated in fp32 (dot rows)
+    for (int li = 0; li < (noview ? D + 1 : D + 4); ++li) {
+        if (folded && (li == iv || li == ife || li == ia)) continue;   // folded: multiplied out / evaluated in fp32 (dot rows)
         const size_t cnt = li < D ? (size_t)W * (li == 0 ? n.in_xyz : (li == n.skip + 1 ? W + n.in_xyz : W))
-                                  : (size_t)in_dims[li - D] * out_dims[li - D];
+                                  : (noview ? (size_t)4 * W : (size_t)in_dims[li - D] * out_dims[li - D]);
         for (size_t k = 0; k < cnt; ++k) wmax = std::max(wmax, (double)std::fabs(w[li][k]));
     }
     for (double v : wv) wmax = std::max(wmax, std::fabs(v));
@@ -222,11 +227,16 @@ void pack_mfma(NetState& n, const float* const* w, const float* const* b) {
         if (i == n.skip + 1) layer(i, W, W + n.in_xyz, W / 32, 0, {{1, 4, 0}, {0, KH, n.in_xyz}});   // cat([pts, h]), nerf_model.py:59
         else layer(i, W, W, W / 32, 0, {{0, KH, 0}});
     }
-    if (!n.folded) {
+    if (noview) {
+        layer(D, 4, W, 1, 1, {{0, KH, 0}});
+        n.n_chunks = (int)(n.bias_tab.size() / 32);
+        return;
+    }
+    if (!folded) {
         layer(ife, W, W, W / 32, 0, {{0, KH, 0}});
         layer(ia, 1, W, 1, 1, {{0, KH, 0}});
     }
-    if (n.folded) {
+    if (folded) {
         RowMap rows{W / 2, 0};
         for (int rt = 0; rt < W / 64; ++rt) put_chunk(n, wv.data(), bv.data(), W + n.in_dir, rows, rt, {{0, KH, 0}, {2, 2, W}});
     } else {
@@ -234,7 +244,7 @@ void pack_mfma(NetState& n, const float* const* w, const float* const* b) {
     }
     layer(irgb, 3, W / 2, 1, 1, {{0, KH / 2, 0}});
     n.n_chunks = (int)(n.bias_tab.size() / 32);
-    if (n.folded) {
+    if (folded) {
         // _alpha_linear (nerf_model.py:63) is not a tile of the folded stream: the kernel accumulates sigma = w . h + b in fp32
         // with the epilogues of the last trunk layer's tiles.  Row rt of the dot table = the weights of trunk features
         // 32 rt .. 32 rt + 31 (the row order of that layer's tile rt, like its bias row), then one row with the bias in front.
@@ -353,7 +363,7 @@ int check_ready(nwe_ctx* ctx, const nwe_outputs* out, int precision) {
     if (precision != NWE_PREC_F32) {
         if (!ctx->net[0].mfma_ok || (ctx->ni > 0 && !ctx->net[1].mfma_ok))
             return fail(ctx, NWE_ERR_UNSUPPORTED,
-                        "no MFMA kernel for this network shape (have widths 128 and 256 with depth 6 or 8 and the skip after layer 4, or depth 4 without, 63/27 inputs); use NWE_PREC_F32");
+                        "no MFMA kernel for this network shape (have widths 128 and 256 with depth 6 or 8 and the skip after layer 4, or depth 4 without, 63/27 inputs; without view directions 8x256 and 4x128 only); use NWE_PREC_F32");
         if (ctx->ns > mfma_max_samples())
             return fail(ctx, NWE_ERR_UNSUPPORTED, "the MFMA kernel supports n_samples <= 128; use NWE_PREC_F32");
     }
@@ -444,11 +454,11 @@ static int set_network_impl(nwe_ctx* c, int which, int depth, int width, int in_
     n.D = depth; n.W = width; n.in_xyz = in_xyz; n.in_dir = in_dir; n.skip = skip_layer; n.out_ch = out_ch;
     n.flops = algo_flops(n);
     pack_f32(n, w, b);
-    n.folded = c->fold != 0;
-    n.mfma_ok = in_dir != 0 && mfma_supported(depth, width, in_xyz, in_dir, skip_layer, n.folded);
+    n.form = in_dir == 0 ? kFormNoViewDirs : (c->fold != 0 ? kFormFolded : kFormReference);
+    n.mfma_ok = mfma_supported(depth, width, in_xyz, in_dir, skip_layer, n.form);
     if (n.mfma_ok) pack_mfma(n, w, b); else { n.stream.clear(); n.bias_tab.clear(); n.n_chunks = 0; }
     n.mf = {};
-    n.mf.D = depth; n.mf.W = width; n.mf.skip = skip_layer; n.mf.folded = n.folded ? 1 : 0;
+    n.mf.D = depth; n.mf.W = width; n.mf.skip = skip_layer; n.mf.form = n.form;
     n.mf.n_tiles = (int)(n.stream.size() / kTileBytes);
     n.mf.n_chunks = n.mfma_ok ? n.n_chunks : 0;
     n.mf.inv_scale = 1.f / n.w_scale;

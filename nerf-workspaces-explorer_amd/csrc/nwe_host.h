@@ -32,11 +32,18 @@ struct NetMfma {
     int n_tiles, n_chunks;
     float inv_scale;        // weights are stored multiplied by 1/inv_scale (a power of two)
     int D, W, skip;
-    int folded;             // 1: _feature_linear multiplied into the view layer at pack time (the stream has no feature chunks)
+    int form;               // Form: which formulation of the network the stream holds
 };
 
-// true if a kernel instantiation exists for this shape
-bool mfma_supported(int D, int W, int in_xyz, int in_dir, int skip, bool folded);
+// The three formulations the MFMA kernel is instantiated for (template argument FORM of nwe_mfma_kernels.h).
+enum Form {
+    kFormReference = 0,     // every layer of nerf_model.py:45-76 as a tile of the stream (selectable for comparison)
+    kFormFolded = 1,        // the product path: _feature_linear multiplied into the view layer at pack time, _alpha_linear a dot product
+    kFormNoViewDirs = 2     // use_view_dirs=False (nerf_model.py:41-43,78-79): trunk, then the rows rgb_raw(3), sigma_raw of _output_linear
+};
+
+// true if a kernel instantiation exists for this shape (in_dir == 0 exactly for kFormNoViewDirs)
+bool mfma_supported(int D, int W, int in_xyz, int in_dir, int skip, int form);
 // returns false if the shape has no instantiation.  decomposition: -1 = pick by frame size, 0 = four ray packets per
 // workgroup, 1 = one packet per workgroup with its samples dealt to the four waves, 2 = full rounds as 0 and the ragged
 // last round as 1 in a second launch (bit-identical results)

@@ -2,5 +2,5 @@
 #include "nwe_mfma_kernels.h"
 
 namespace nwe {
-template bool launch_t<256, 8, 4, true>(const RenderArgs&, const NetMfma&, const NetMfma&, bool, int, hipStream_t, LaunchInfo*);
+template bool launch_t<256, 8, 4, kFormFolded>(const RenderArgs&, const NetMfma&, const NetMfma&, bool, int, hipStream_t, LaunchInfo*);
 }  // namespace nwe

@@ -2,6 +2,6 @@
 #include "nwe_mfma_kernels.h"
 
 namespace nwe {
-template bool launch_t<256, 8, 4, false>(const RenderArgs&, const NetMfma&, const NetMfma&, bool, int, hipStream_t, LaunchInfo*);
-template bool launch_t<256, 4, -1, true>(const RenderArgs&, const NetMfma&, const NetMfma&, bool, int, hipStream_t, LaunchInfo*);
+template bool launch_t<256, 8, 4, kFormReference>(const RenderArgs&, const NetMfma&, const NetMfma&, bool, int, hipStream_t, LaunchInfo*);
+template bool launch_t<256, 4, -1, kFormFolded>(const RenderArgs&, const NetMfma&, const NetMfma&, bool, int, hipStream_t, LaunchInfo*);
 }  // namespace nwe

@@ -2,6 +2,6 @@
 #include "nwe_mfma_kernels.h"
 
 namespace nwe {
-template bool launch_t<256, 6, 4, true>(const RenderArgs&, const NetMfma&, const NetMfma&, bool, int, hipStream_t, LaunchInfo*);
-template bool launch_t<128, 4, -1, false>(const RenderArgs&, const NetMfma&, const NetMfma&, bool, int, hipStream_t, LaunchInfo*);
+template bool launch_t<256, 6, 4, kFormFolded>(const RenderArgs&, const NetMfma&, const NetMfma&, bool, int, hipStream_t, LaunchInfo*);
+template bool launch_t<128, 4, -1, kFormReference>(const RenderArgs&, const NetMfma&, const NetMfma&, bool, int, hipStream_t, LaunchInfo*);
 }  // namespace nwe

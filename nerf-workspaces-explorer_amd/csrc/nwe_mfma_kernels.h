@@ -64,6 +64,10 @@ struct Shape {
     // rows of the bias table (row rt, element i = weight of trunk feature 32 rt + i) plus one row whose element 0 is its bias.
     static constexpr int N_CHUNKS_FOLDED = N_CHUNKS - NT - 1;
     static constexpr int N_DOT_ROWS = NT + 1;
+    // kFormNoViewDirs: layer 0, D-1 trunk layers, one chunk of _output_linear (nerf_model.py:42-43,78-79)
+    static constexpr int N_CHUNKS_NOVIEW = D * NT + 1;
+    static constexpr int n_chunks(int form) { return form == kFormFolded ? N_CHUNKS_FOLDED : (form == kFormNoViewDirs ? N_CHUNKS_NOVIEW : N_CHUNKS); }
+    static constexpr int n_bias_rows(int form) { return n_chunks(form) + (form == kFormFolded ? N_DOT_ROWS : 0); }
     // A LONG chunk (>= 16 k-steps, three-pass mode) keeps the (hi, lo) tiles of its last k-step in a rotating tail slot
     // instead of the chunk buffer, see Walker.
     static constexpr int LONG_PIECES = 8;
@@ -661,8 +665,9 @@ __device__ __forceinline__ void tile_mma(WalkerT& wk, Frags& F, int lane, bool u
 // k-steps 2*NT-2, 2*NT-1 of X itself), for rt > 0 tile rt-1 of this layer (destined for Y).  On return P1 holds
 // this layer's last tile, still pending.  Chunk sizes for the DMA schedule, in pieces per wave: this layer's chunks
 // N_THIS (+2 when use_g), the following layer's N_AFTER (+2 when extra_after), and `first_nb` = what tile 0 still
-// has to issue of chunk T+1 (0 at the very start of a pass, where chunks 0 and 1 are streamed up front).
-template <int NT, int NKP, int NKH, bool X3, bool PEND0, int N_AFTER, bool PASS_START, bool DOT = false, class WalkerT>
+// has to issue of chunk T+1 (0 at the very start of a pass, where chunks 0 and 1 are streamed up front).  NA_LAST: what the
+// layer's last tile starts of chunk T+2 - N_AFTER unless only ONE chunk follows the layer (kFormNoViewDirs: 0).
+template <int NT, int NKP, int NKH, bool X3, bool PEND0, int N_AFTER, bool PASS_START, bool DOT = false, int NA_LAST = N_AFTER, class WalkerT>
 __device__ __forceinline__ void layer(WalkerT& wk, Frags& F, int lane, bool use_g, bool extra_after, const h8* Ghi, const h8* Glo,
                                       h8* Xhi, h8* Xlo, h8* Yhi, h8* Ylo, Pend& P0, Pend& P1, float inv_scale, float lower_prev,
                                       float lower, int na_last_override = -1, const float* dot_tab = nullptr, float* dot = nullptr) {
@@ -698,7 +703,7 @@ __device__ __forceinline__ void layer(WalkerT& wk, Frags& F, int lane, bool use_
                                                                       prev, inv_scale, lower, Yhi[2 * rt - 2], Ylo[2 * rt - 2], Yhi[2 * rt - 1],
                                                                       Ylo[2 * rt - 1], -1, drow, dot);
         } else {
-            tile_mma<NKP, NKH, 0, 0, X3, true, N_AFTER, N_AFTER, true, false, DOT>(wk, F, lane, use_g, ebB, ebA, Ghi, Glo, Xhi, Xlo, nullptr, nullptr, cur,
+            tile_mma<NKP, NKH, 0, 0, X3, true, N_AFTER, NA_LAST, true, false, DOT>(wk, F, lane, use_g, ebB, ebA, Ghi, Glo, Xhi, Xlo, nullptr, nullptr, cur,
                                                                        prev, inv_scale, lower, Yhi[2 * rt - 2], Ylo[2 * rt - 2], Yhi[2 * rt - 1],
                                                                        Ylo[2 * rt - 1], na_last_override, drow, dot);
         }
@@ -782,14 +787,18 @@ __device__ __forceinline__ void view_tiles(WalkerT& wk, Frags& F, int lane, h8* 
 // one single layer A->B, then _alpha_linear and the folded view layer both read B = h, the rgb head reads the view layer's
 // output in A.  !FOLD evaluates the feature layer as the reference formulates it (D/2 pairs, the last pair's second layer
 // is the feature layer without ReLU; alpha reads B, the view layer A); kept selectable for comparison.
+// kFormNoViewDirs (use_view_dirs=False, nerf_model.py:42-43,78-79): the trunk as in FOLD (D/2 - 1 pairs and the single last
+// layer A -> B, without the dot product), then ONE tile of _output_linear on B = h whose rows 0..3 are rgb_raw, sigma_raw
+// (copies in rows 4..7 for the upper lane half; the reference ignores the fifth channel too: model_utils.py:62,71).
 // On entry chunks 0 and 1 of the stream are visible / in flight and F holds the first PD k-steps of chunk 0.
-template <int W, int D, int SKIP, bool X3, bool FOLD, class WalkerT>
+template <int W, int D, int SKIP, bool X3, int FORM, class WalkerT>
 __device__ __forceinline__ void mlp_eval(WalkerT& wk, Frags& F, int lane, float inv_scale, h8* Ghi, h8* Glo, const char* gd_lds,
                                          const float* dot_tab, float& o_r, float& o_g, float& o_b, float& o_s) {
     using S = Shape<W, D>;
     static_assert(D % 2 == 0, "trunk depth must be even");
     static_assert(SKIP < 0 || SKIP % 2 == 0, "skip layer index must be even");
     static_assert(S::NT % 2 == 0 && S::NTV % 2 == 0, "tile counts must be even");
+    constexpr bool FOLD = FORM == kFormFolded, NOVIEW = FORM == kFormNoViewDirs;
     h8 Ahi[S::KH], Alo[S::KH], Bhi[S::KH], Blo[S::KH];
     Pend P0, P1;
     constexpr int NPAIR = D / 2;
@@ -808,10 +817,10 @@ __device__ __forceinline__ void mlp_eval(WalkerT& wk, Frags& F, int lane, float 
         // second of pair: B -> A; !FOLD: the last pair's second layer is _feature_linear (no ReLU, nerf_model.py:64).
         // After it comes the next pair's first layer (skip: 2 more pieces) or the alpha tile and then the view layer.
         layer<S::NT, 0, S::KH, X3, true, S::N_H, false>(wk, F, lane, false, skip_next, nullptr, nullptr, Bhi, Blo,
-                                                        Ahi, Alo, P0, P1, inv_scale, 0.f, (!FOLD && last) ? -INFINITY : 0.f,
-                                                        (!FOLD && last) ? S::N_V : -1);
+                                                        Ahi, Alo, P0, P1, inv_scale, 0.f, (FORM == kFormReference && last) ? -INFINITY : 0.f,
+                                                        (FORM == kFormReference && last) ? S::N_V : -1);
     };
-    constexpr int PAIRS = FOLD ? NPAIR - 1 : NPAIR;   // pairs evaluated here (FOLD: the last trunk layer stands alone below)
+    constexpr int PAIRS = FORM == kFormReference ? NPAIR : NPAIR - 1;   // pairs evaluated here (otherwise the last trunk layer stands alone below)
 #ifndef NWE_PEEL_SKIP
 #define NWE_PEEL_SKIP 1   // the pair that takes gamma(x) is peeled out of the rolled loop: no run-time use_g tests inside the tiles (6 branches per tile of every first-of-pair layer), +16 tiles of code (110 KB): -0.8 % (364.4 vs 367.2 ms, alternating); 0 = one rolled loop
 #endif
@@ -840,6 +849,21 @@ __device__ __forceinline__ void mlp_eval(WalkerT& wk, Frags& F, int lane, float 
     }
     constexpr int L = 2 * S::NT - 2;
     constexpr int LV = 2 * S::NTV - 2;
+    if constexpr (NOVIEW) {
+        // the last trunk layer A -> B: ONE chunk follows it (N_H pieces per wave), so its last tile starts no chunk T+2
+        constexpr bool G_LAST = SKIP_PAIR == NPAIR - 1;
+        layer<S::NT, G_LAST ? S::KG : 0, S::KH, X3, true, S::N_H, false, false, 0>(wk, F, lane, G_LAST, false, Ghi, Glo, Ahi, Alo, Bhi, Blo, P0, P1,
+                                                                                   inv_scale, 0.f, 0.f);
+        // _output_linear in P0 while the last trunk tile (P1, NT even) is finished - ReLU - into the last two k-steps of B, which
+        // this tile itself reads (FEEDS).  Nothing is streamed behind it: the caller starts the next pass.
+        tile_mma<0, S::KH, 0, 0, X3, true, 0, 0, false, true>(wk, F, lane, false, false, false, nullptr, nullptr, Bhi, Blo, nullptr, nullptr, P0,
+                                                              P1, inv_scale, 0.f, Bhi[L], Blo[L], Bhi[L + 1], Blo[L + 1]);
+        o_r = pend_value(P0, 0, inv_scale);
+        o_g = pend_value(P0, 1, inv_scale);
+        o_b = pend_value(P0, 2, inv_scale);
+        o_s = pend_value(P0, 3, inv_scale);
+        return;
+    }
     static_assert((S::NTV * (S::KH + S::KD)) % (PD + 1) == 0, "the view tiles must restore the ring phase");
     // gamma(d) is per-ray, used by the view layer only: it waits in LDS (this lane's 16 bytes of each fragment tile) instead
     // of holding 16 registers through the trunk.  Read behind the trunk's last barrier, long before the view tiles' k-steps
@@ -925,7 +949,7 @@ __host__ __device__ inline bool is_lean(const RenderArgs& a) {
            !a.raw_in_f && !a.w_in && !a.t_rand && !a.noise_c && !a.noise_f && !a.u_rand && !a.stamps && !a.rays;
 }
 
-template <int W, int D, int SKIP, bool X3, bool SPLIT, bool FOLD, bool LEAN>
+template <int W, int D, int SKIP, bool X3, bool SPLIT, int FORM, bool LEAN>
 __global__ void __launch_bounds__(256) render_mfma_kernel(RenderArgs a_in, NetMfma nc, NetMfma nf) {
     RenderArgs a = a_in;
     if constexpr (LEAN) {
@@ -950,8 +974,8 @@ __global__ void __launch_bounds__(256) render_mfma_kernel(RenderArgs a_in, NetMf
     for (int i = threadIdx.x; i < ns; i += 256) { s_t[i] = a.t_vals[i]; s_omt[i] = a.omt_vals[i]; }
     for (int i = threadIdx.x; i < ni; i += 256) s_u[i] = a.u_vals[i];
     float* s_bias = reinterpret_cast<float*>(smem + SM::BOFF);
-    constexpr int NCH = FOLD ? S::N_CHUNKS_FOLDED : S::N_CHUNKS;   // the launcher checks n_chunks of both networks against it
-    constexpr int NROWS = NCH + (FOLD ? S::N_DOT_ROWS : 0);        // FOLD: the alpha layer's weights and bias ride behind the bias rows
+    constexpr int NCH = S::n_chunks(FORM);       // the launcher checks n_chunks of both networks against it
+    constexpr int NROWS = S::n_bias_rows(FORM);  // kFormFolded: the alpha layer's weights and bias ride behind the bias rows
     static_assert(NROWS * 32 * 4 <= SM::BIAS_BYTES, "bias table too small for the dot rows");
     for (int i = threadIdx.x; i < NROWS * 32; i += 256) {
         s_bias[i] = nc.bias[i];
@@ -983,7 +1007,7 @@ __global__ void __launch_bounds__(256) render_mfma_kernel(RenderArgs a_in, NetMf
 
     // gamma(d): once per ray (model_utils.py:23-25 re-embeds the same direction for every sample), parked in LDS
     char* gd_lds = smem + SM::GOFF + wave * (2 * S::KD * kTileBytes) + lane * 16;
-    {
+    if constexpr (FORM != kFormNoViewDirs) {
         const Ray rv = make_ray<true>(a, seed);
         h8 GDhi[S::KD], GDlo[S::KD];
         encode<2, S::KD, X3>(rv.vx, rv.vy, rv.vz, half, GDhi, GDlo);
@@ -1120,7 +1144,7 @@ __global__ void __launch_bounds__(256) render_mfma_kernel(RenderArgs a_in, NetMf
                 wk.st_t0 = t2;
                 st_sync += t2 - t1;
 #endif
-                mlp_eval<W, D, SKIP, X3, FOLD>(wk, F, lane, net.inv_scale, Ghi, Glo, gd_lds, dot_tab, rr, rg, rb, rs);
+                mlp_eval<W, D, SKIP, X3, FORM>(wk, F, lane, net.inv_scale, Ghi, Glo, gd_lds, dot_tab, rr, rg, rb, rs);
 #ifdef NWE_STAMPS
                 st_mlp += __builtin_amdgcn_s_memtime() - t2;
 #endif
@@ -1209,7 +1233,7 @@ __global__ void __launch_bounds__(256) render_mfma_kernel(RenderArgs a_in, NetMf
                 wk.st_t0 = t2;
                 st_sync += t2 - t1;
     #endif
-                mlp_eval<W, D, SKIP, X3, FOLD>(wk, F, lane, net.inv_scale, Ghi, Glo, gd_lds, dot_tab, rr, rg, rb, rs);
+                mlp_eval<W, D, SKIP, X3, FORM>(wk, F, lane, net.inv_scale, Ghi, Glo, gd_lds, dot_tab, rr, rg, rb, rs);
     #ifdef NWE_STAMPS
                 st_mlp += __builtin_amdgcn_s_memtime() - t2;
     #endif
@@ -1250,7 +1274,7 @@ __global__ void __launch_bounds__(256) render_mfma_kernel(RenderArgs a_in, NetMf
 #endif
 }
 
-template <int W, int D, int SKIP, bool FOLD>
+template <int W, int D, int SKIP, int FORM>
 inline void launch_one(RenderArgs a, const NetMfma& nc, const NetMfma& nf, bool three_pass, bool split, int64_t ray_first, int64_t rays,
                        hipStream_t stream) {
     if (rays <= 0) return;
@@ -1258,7 +1282,7 @@ inline void launch_one(RenderArgs a, const NetMfma& nc, const NetMfma& nf, bool 
     const int64_t per_wg = split ? kRaysPerWave : kWaves * kRaysPerWave;
     const unsigned blocks = (unsigned)((rays + per_wg - 1) / per_wg);
 #define NWE_LAUNCH(X3_, SPLIT_, LEAN_) \
-    hipLaunchKernelGGL((render_mfma_kernel<W, D, SKIP, X3_, SPLIT_, FOLD, LEAN_>), dim3(blocks), dim3(256), 0, stream, a, nc, nf)
+    hipLaunchKernelGGL((render_mfma_kernel<W, D, SKIP, X3_, SPLIT_, FORM, LEAN_>), dim3(blocks), dim3(256), 0, stream, a, nc, nf)
     const bool lean = is_lean(a);
     if (three_pass) {
         if (split) { if (lean) NWE_LAUNCH(true, true, true); else NWE_LAUNCH(true, true, false); }
@@ -1270,11 +1294,11 @@ inline void launch_one(RenderArgs a, const NetMfma& nc, const NetMfma& nf, bool 
 #undef NWE_LAUNCH
 }
 
-template <int W, int D, int SKIP, bool FOLD>
+template <int W, int D, int SKIP, int FORM>
 bool launch_t(const RenderArgs& a, const NetMfma& nc, const NetMfma& nf, bool three_pass, int decomposition, hipStream_t stream,
                      LaunchInfo* info) {
     using S = Shape<W, D>;
-    constexpr int NCH = FOLD ? S::N_CHUNKS_FOLDED : S::N_CHUNKS;
+    constexpr int NCH = S::n_chunks(FORM);
     if (nc.n_chunks != NCH || (a.n_importance > 0 && nf.n_chunks != NCH)) return false;   // the kernel copies NCH bias rows
     // One workgroup per CU at a time, so a launch costs (rounds of workgroups) x (sample iterations per workgroup).  Three
     // plans, same arithmetic: all packets; all sample-split (finer units, ~6 % overhead: redundant sequential part and
@@ -1298,11 +1322,11 @@ bool launch_t(const RenderArgs& a, const NetMfma& nc, const NetMfma& nf, bool th
     if (a.n_samples > kPacketMaxSamples) plan = 1;  // only the single-packet workgroup has LDS for that many coarse weights
     if (info) { info->plan = plan; info->rays_first = plan == 2 ? full : a.n_rays; info->mid_recorded = false; }
     if (plan == 2) {
-        launch_one<W, D, SKIP, FOLD>(a, nc, nf, three_pass, false, 0, full, stream);
+        launch_one<W, D, SKIP, FORM>(a, nc, nf, three_pass, false, 0, full, stream);
         if (info && info->mid) info->mid_recorded = hipEventRecord(info->mid, stream) == hipSuccess;   // the two launches timed apart
-        launch_one<W, D, SKIP, FOLD>(a, nc, nf, three_pass, true, full, a.n_rays - full, stream);
+        launch_one<W, D, SKIP, FORM>(a, nc, nf, three_pass, true, full, a.n_rays - full, stream);
     } else {
-        launch_one<W, D, SKIP, FOLD>(a, nc, nf, three_pass, plan == 1, 0, a.n_rays, stream);
+        launch_one<W, D, SKIP, FORM>(a, nc, nf, three_pass, plan == 1, 0, a.n_rays, stream);
     }
     return true;
 }

@@ -85,9 +85,9 @@ class NeRFReplicaInferenceHandler:
         self._img_w = cfg.get_param(("experiment", "image_width"), int)
         self._depth_close_bound, self._depth_far_bound = cfg.get_param(("rendering", "depth_range"), list)
         # rendering.use_view_dirs = False (nerf_model.py:41-43,82-83) and experiment.endpoint_feat = True (:72-81, handler.py:248-271)
-        # are off in all four reference YAMLs; both render here: networks without view directions through the fp32 HIP kernel
-        # (no MFMA instantiation), the endpoint feature map as `feat_map_fine` of _render_rays (fp32 kernel too; frames, which
-        # return rgb only, keep the MFMA kernel).
+        # are off in all four reference YAMLs; both render here: networks without view directions through the MFMA kernel's
+        # own instantiations (8x256 and 4x128; other shapes through the fp32 HIP kernel), the endpoint feature map as
+        # `feat_map_fine` of _render_rays (fp32 kernel; frames, which return rgb only, keep the MFMA kernel).
         self._fx, self._fy, self._cx, self._cy = pinhole_intrinsics(self._img_h, self._img_w)
         self._renderer: Optional[Renderer] = None
         self._stage: Optional[torch.Tensor] = None   # pinned uint8 [H,W,3] staging buffer for render_coordinates

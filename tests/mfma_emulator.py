@@ -94,13 +94,24 @@ def layer(st, n_tiles, segs, lower, three_pass=True):
     return np.concatenate(his, 0), np.concatenate(los, 0)
 
 
-def mlp_eval(stream_bytes, bias_tab, scale, pts, dirs, D, W, skip, three_pass=True, folded=True):
+def mlp_eval(stream_bytes, bias_tab, scale, pts, dirs, D, W, skip, three_pass=True, folded=True, no_view_dirs=False):
     """pts [n,3] (already divided by 10), dirs [n,3] -> raw [n,4] as the kernel would produce.  folded: the stream has no
-    feature-layer chunks (the packer multiplied _feature_linear into the view layer), the kernel's FOLD path."""
+    feature-layer chunks (the packer multiplied _feature_linear into the view layer), the kernel's FOLD path.
+    no_view_dirs (dirs unused): the trunk, then one chunk of _output_linear whose rows 0..3 are rgb_raw, sigma_raw
+    (kFormNoViewDirs)."""
     st = Stream(stream_bytes, bias_tab, scale)
     G = encode(pts.T.astype(np.float32), 5, 4)
-    GD = encode(dirs.T.astype(np.float32), 2, 2)
     NT = W // 32
+    if no_view_dirs:
+        A = layer(st, NT, [G], 0.0, three_pass)
+        for li in range(1, D):                             # trunk layers 1..D-1, ReLU each (nerf_model.py:55-59)
+            A = layer(st, NT, ([G] if li == skip + 1 and skip >= 0 else []) + [A], 0.0, three_pass)
+        t = mma_tile(st, [A], three_pass)                  # _output_linear (:78-79)
+        assert np.array_equal(t[0:4], t[4:8]), "output tile rows 4..7 must copy rows 0..3"
+        assert st.pos == len(stream_bytes), (st.pos, len(stream_bytes))
+        assert st.chunk == len(bias_tab), (st.chunk, len(bias_tab))
+        return np.stack([t[0], t[1], t[2], t[3]], axis=1)
+    GD = encode(dirs.T.astype(np.float32), 2, 2)
     A = layer(st, NT, [G], 0.0, three_pass)
     npair = D // 2
     skip_pair = -1 if skip < 0 else skip // 2

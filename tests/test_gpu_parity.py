@@ -1195,8 +1195,9 @@ def _variant_rays(g, use_view_dirs):
 def test_networks_without_view_dirs(golden_dir, tmp_path, monkeypatch, capsys):
     """NeRFModel(use_view_dirs=False) (nerf_model.py:41-43,82-83): trunk + _output_linear [5, W], 8-column rays (rays.py:22-30),
     against tests/golden/variants.npz (the reference's own classes): the network alone at the embed.npz points, then 16 + 24
-    samples end to end with a thin-fog coarse network (every ray at full tolerance); the fp32 HIP kernel serves it (no MFMA
-    instantiation - asked for explicitly it is refused, never silently replaced), also through the handler with
+    samples end to end with a thin-fog coarse network (every ray at full tolerance) - through the fp32 HIP kernel and through
+    the MFMA kernel's kFormNoViewDirs instantiations (8x256 and 4x128; another shape asked for explicitly is refused, never
+    silently replaced), a 200x200 frame of the MFMA kernel against the fp32 kernel, and the handler with
     rendering.use_view_dirs: False in its YAML."""
     g = np.load(os.path.join(golden_dir, "variants.npz"))
     ge = np.load(os.path.join(golden_dir, "embed.npz"))
@@ -1205,14 +1206,16 @@ def test_networks_without_view_dirs(golden_dir, tmp_path, monkeypatch, capsys):
     for tag, D, Wn, seed in (("4x128", 4, 128, 2000), ("8x256", 8, 256, 2001)):
         r = nwe_amd.Renderer(0)
         assert r.set_network(0, nwe_amd.synthetic.make_state_dict(seed, D, Wn, use_view_dirs=False))[3] == 0 and r.ray_columns == 8
-        assert not r.mfma_supported(0)
+        assert r.mfma_supported(0)
         r.set_sampling(2, 0)
-        raw = r.render_rays(rays_pts, precision="f32", outputs=("raw_coarse",))["raw_coarse"].cpu().numpy()
-        err = np.abs(raw[:, 0] - g[f"novd_y_{tag}"][:, :4]).max()
-        print(f"[no view dirs {tag}] raw vs the reference's NeRFModel: {err:.2e}")
-        assert err <= 5e-6
-        with pytest.raises(NotImplementedError):
-            r.render_rays(rays_pts, precision="f16x3", outputs=("raw_coarse",))
+        for prec, tol in (("f32", 5e-6), ("f16x3", 5e-6), ("f16x1", 5e-2)):
+            for mode in ((-1,) if prec == "f32" else (0, 1)):       # both work decompositions of the MFMA kernel
+                r.debug_set_decomposition(mode)
+                raw = r.render_rays(rays_pts, precision=prec, outputs=("raw_coarse",))["raw_coarse"].cpu().numpy()
+                err = np.abs(raw[:, 0] - g[f"novd_y_{tag}"][:, :4]).max()
+                print(f"[no view dirs {tag} {prec} decomposition {mode}] raw vs the reference's NeRFModel: {err:.2e}")
+                assert err <= tol
+        r.debug_set_decomposition(-1)
         with pytest.raises(ValueError, match="R,8"):
             r.render_rays(torch.zeros(4, 11, device="cuda"), precision="f32")
         r.close()
@@ -1221,15 +1224,27 @@ def test_networks_without_view_dirs(golden_dir, tmp_path, monkeypatch, capsys):
     rays8 = _variant_rays(g, False)
     r = nwe_amd.Renderer(0)
     r.set_network(0, sd_c); r.set_network(1, sd_f); r.set_sampling(16, 24)
-    out = r.render_rays(rays8.cuda(), precision="f32", outputs=("rgb", "depth", "acc", "z_std", "rgb_coarse", "depth_coarse", "acc_coarse", "z_fine", "raw_fine"))
     cliff = np.abs(g["novd_sigma_last_fine"]) < 1e-5
-    errs = {k: float(np.abs(out[k].cpu().numpy() - g["novd_" + n])[~cliff].max()) for k, n in
-            (("rgb", "rgb_fine"), ("depth", "depth_fine"), ("acc", "acc_fine"), ("z_std", "z_std"), ("rgb_coarse", "rgb_coarse"),
-             ("depth_coarse", "depth_coarse"), ("acc_coarse", "acc_coarse"), ("z_fine", "z_fine"))}
-    print("[no view dirs, end to end]", {k: f"{v:.1e}" for k, v in errs.items()})
-    assert errs["rgb"] <= RGB_TOL and errs["rgb_coarse"] <= RGB_TOL and errs["depth"] / FAR <= 1e-4 and errs["acc"] <= 1e-4
-    assert errs["z_fine"] <= 1e-4 and errs["z_std"] <= 1e-4
-    assert np.abs(out["raw_fine"].cpu().numpy()[:32] - g["novd_raw_fine_first32"][..., :4]).max() <= 2e-4   # at slightly moved depths
+    for prec in ("f32", "f16x3"):
+        out = r.render_rays(rays8.cuda(), precision=prec, outputs=("rgb", "depth", "acc", "z_std", "rgb_coarse", "depth_coarse", "acc_coarse", "z_fine", "raw_fine"))
+        errs = {k: float(np.abs(out[k].cpu().numpy() - g["novd_" + n])[~cliff].max()) for k, n in
+                (("rgb", "rgb_fine"), ("depth", "depth_fine"), ("acc", "acc_fine"), ("z_std", "z_std"), ("rgb_coarse", "rgb_coarse"),
+                 ("depth_coarse", "depth_coarse"), ("acc_coarse", "acc_coarse"), ("z_fine", "z_fine"))}
+        print(f"[no view dirs, end to end, {prec}]", {k: f"{v:.1e}" for k, v in errs.items()})
+        assert errs["rgb"] <= RGB_TOL and errs["rgb_coarse"] <= RGB_TOL and errs["depth"] / FAR <= 1e-4 and errs["acc"] <= 1e-4
+        assert errs["z_fine"] <= 1e-4 and errs["z_std"] <= 1e-4
+        assert np.abs(out["raw_fine"].cpu().numpy()[:32] - g["novd_raw_fine_first32"][..., :4]).max() <= 2e-4   # at slightly moved depths
+    # a frame: pinhole rays, the lean instantiation, 64 + 128 samples, the hybrid launch plan - the MFMA kernel against the fp32 kernel
+    r.set_sampling(64, 128)
+    fx, fy, cx, cy = O.intrinsics(200, 200)
+    frame = {prec: r.render(g["novd_pose"], 200, 200, fx=fx, fy=fy, cx=cx, cy=cy, near=0.1, far=10.0, precision=prec) for prec in ("f32", "f16x3")}
+    plan = r.debug_last_plan()
+    d_rgb = (frame["f16x3"]["rgb"] - frame["f32"]["rgb"]).abs().max().item()
+    d_depth = (frame["f16x3"]["depth"] - frame["f32"]["depth"]).abs().max().item()
+    print(f"[no view dirs, 200x200 frame] MFMA vs fp32 kernel: rgb {d_rgb:.1e}, depth {d_depth:.1e}, launch plan {plan}, "
+          f"{r.last_kernel_ms():.2f} ms")
+    assert d_rgb <= RGB_TOL and d_depth / FAR <= 1e-4 and frame["f16x3"]["rgb"].std().item() > 0.01
+    r.set_sampling(16, 24)
     # create_rays without the view-direction columns: the first eight columns, bit for bit
     fx, fy, cx, cy = O.intrinsics(800, 800)
     mine = r.create_rays(g["novd_pose"], 800, 800, fx=fx, fy=fy, cx=cx, cy=cy, near=0.1, far=10.0, rows=(0, 2), use_view_dirs=False)
@@ -1238,6 +1253,14 @@ def test_networks_without_view_dirs(golden_dir, tmp_path, monkeypatch, capsys):
     r.set_network(1, nwe_amd.synthetic.make_state_dict(1001, 8, 256))
     with pytest.raises(RuntimeError, match="both have, or both lack"):
         r.render_rays(rays8.cuda(), precision="f32")
+    r.close()
+    # a shape without an MFMA instantiation: refused when asked for, the fp32 kernel serves it
+    r = nwe_amd.Renderer(0)
+    r.set_network(0, nwe_amd.synthetic.make_state_dict(2003, 6, 256, use_view_dirs=False)); r.set_sampling(2, 0)
+    assert not r.mfma_supported(0)
+    with pytest.raises(NotImplementedError):
+        r.render_rays(rays_pts, precision="f16x3", outputs=("raw_coarse",))
+    assert torch.isfinite(r.render_rays(rays_pts, precision="f32", outputs=("raw_coarse",))["raw_coarse"]).all()
     r.close()
     # through the handler: a YAML with use_view_dirs: False
     import yaml
@@ -1251,7 +1274,10 @@ def test_networks_without_view_dirs(golden_dir, tmp_path, monkeypatch, capsys):
     with pytest.raises(RuntimeError, match="view-direction heads"):
         h.initialize_models(state_dicts=(_sd(1000, 8, 256), _sd(1001, 8, 256)))
     h.initialize_models(state_dicts=(sd_c, sd_f))
-    assert "no MFMA instantiation" in capsys.readouterr().out
+    said = capsys.readouterr().out
+    with capsys.disabled():
+        print(said, end="")            # the figures above, visible under -s although this test captures
+    assert "no MFMA instantiation" not in said and h._precision == "f16x3"
     res = h._render_rays(rays8.cuda())
     assert np.abs(res["rgb_fine"].cpu().numpy() - g["novd_rgb_fine"])[~cliff].max() <= RGB_TOL
     init, loc = nwe_amd.COORD(x=0.0, y=-0.5, z=-0.76, pitch=-90.0), nwe_amd.COORD(yaw=-30.0)

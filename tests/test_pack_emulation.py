@@ -42,6 +42,43 @@ def test_stream_replay_matches_oracle(D, W, seed, folded, n_tiles, n_chunks):
     assert 2e-5 < np.abs(got1 - ref).max() < 5e-2
 
 
+@pytest.mark.parametrize("D,W,seed", [(8, 256, 21), (4, 128, 22)])
+def test_stream_replay_without_view_dirs(D, W, seed):
+    """use_view_dirs=False (nerf_model.py:42-43,78-79): layer 0, D-1 trunk layers and ONE chunk of _output_linear - rows 0..3,
+    the fifth channel is dropped as the reference drops it (model_utils.py:62,71)."""
+    sd = nwe_amd.synthetic.make_state_dict(seed, D, W, use_view_dirs=False)
+    r = nwe_amd.Renderer(host_only=True)
+    shape = r.set_network(0, sd)
+    assert r.mfma_supported(0)
+    stream, bias, scale = r.packed_stream(0), r.packed_bias(0), r.packed_scale(0)
+    NT, KH = W // 32, W // 16
+    skip_tiles = NT * 2 * 4 if D > 5 else 0                                 # the skip layer's four gamma(x) k-steps
+    assert stream.size == (NT * 2 * 4 + (D - 1) * NT * 2 * KH + skip_tiles + 2 * KH) * 1024
+    assert bias.shape == (D * NT + 1, 32)
+    wo, bo = sd["_output_linear.weight"], sd["_output_linear.bias"]
+    assert np.array_equal(bias[-1, :4], bo[:4]) and np.array_equal(bias[-1, 4:8], bo[:4]) and not bias[-1, 8:].any()
+    # the ignored fifth row must not shrink the scale: make it huge and pack again
+    big = dict(sd)
+    big["_output_linear.weight"] = wo.copy()
+    big["_output_linear.weight"][4] *= 1e4
+    r2 = nwe_amd.Renderer(host_only=True)
+    r2.set_network(0, big)
+    assert r2.packed_scale(0) == scale and np.array_equal(r2.packed_stream(0), stream)
+    g = torch.Generator().manual_seed(4)
+    pts = (torch.rand(32, 3, generator=g) * 2 - 1) * torch.tensor([8.0, 3.0, 1.0])
+    ref = O.mlp_forward({k: torch.from_numpy(v) for k, v in sd.items()}, O.embed(pts, 10, 10)).numpy()[:, :4]
+    got = E.mlp_eval(stream, bias, scale, (pts / 10).numpy(), None, D, W, shape[4], three_pass=True, no_view_dirs=True)
+    assert np.abs(got - ref).max() < 2e-5, np.abs(got - ref).max()
+    got1 = E.mlp_eval(stream, bias, scale, (pts / 10).numpy(), None, D, W, shape[4], three_pass=False, no_view_dirs=True)
+    assert 2e-5 < np.abs(got1 - ref).max() < 5e-2
+
+
+def test_no_view_dirs_stream_only_for_the_baseline_shapes():
+    r = nwe_amd.Renderer(host_only=True)
+    r.set_network(0, nwe_amd.synthetic.make_state_dict(5, 6, 256, use_view_dirs=False))
+    assert r.packed_stream(0).size == 0 and not r.mfma_supported(0)      # the fp32 kernel serves it
+
+
 def test_unfolded_stream_only_for_the_baseline_shapes():
     r = nwe_amd.Renderer(host_only=True)
     r.debug_set_fold(False)

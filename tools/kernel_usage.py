@@ -4,9 +4,9 @@ t = open(sys.argv[1] if len(sys.argv) > 1 else "nerf-workspaces-explorer_amd/csr
 for b in re.split(r"remark: [^\n]*Function Name: ", t)[1:]:
     name = b.split("\n")[0]
     g = lambda k: re.search(k + r": (\d+)", b).group(1)
-    m = re.search(r"render_mfma_kernelILi(\d+)ELi(\d+)ELi(-?\w+)ELb(\d)ELb(\d)ELb(\d)ELb(\d)", name)
+    m = re.search(r"render_mfma_kernelILi(\d+)ELi(\d+)ELi(-?\w+)ELb(\d)ELb(\d)ELi(\d)ELb(\d)", name)
     if m:
         W, D, S, x3, sp, fo, lean = m.groups()
         scratch, lds = g(r"ScratchSize \[bytes/lane\]"), g(r"LDS Size \[bytes/block\]")
-        print(f"W={W} D={D} skip={S.replace('n', '-')} X3={x3} SPLIT={sp} FOLD={fo} LEAN={lean}  VGPR {g('VGPRs')} AGPR {g('AGPRs')} SGPR {g('TotalSGPRs')} "
+        print(f"W={W} D={D} skip={S.replace('n', '-')} X3={x3} SPLIT={sp} FORM={fo} LEAN={lean}  VGPR {g('VGPRs')} AGPR {g('AGPRs')} SGPR {g('TotalSGPRs')} "
               f"scratch {scratch} LDS {lds}")
