@@ -1244,6 +1244,16 @@ def test_networks_without_view_dirs(golden_dir, tmp_path, monkeypatch, capsys):
     print(f"[no view dirs, 200x200 frame] MFMA vs fp32 kernel: rgb {d_rgb:.1e}, depth {d_depth:.1e}, launch plan {plan}, "
           f"{r.last_kernel_ms():.2f} ms")
     assert d_rgb <= RGB_TOL and d_depth / FAR <= 1e-4 and frame["f16x3"]["rgb"].std().item() > 0.01
+    # repeated, and through the full instantiation (diagnostic outputs requested), and in ONE launch of either decomposition: the same bits
+    again = r.render(g["novd_pose"], 200, 200, fx=fx, fy=fy, cx=cx, cy=cy, near=0.1, far=10.0, precision="f16x3")
+    full = r.render(g["novd_pose"], 200, 200, fx=fx, fy=fy, cx=cx, cy=cy, near=0.1, far=10.0, precision="f16x3",
+                    outputs=("rgb", "depth", "acc", "z_std", "rgb_coarse"))
+    assert all(torch.equal(again[k], frame["f16x3"][k]) and torch.equal(full[k], frame["f16x3"][k]) for k in ("rgb", "depth", "acc"))
+    for mode in (0, 1):
+        r.debug_set_decomposition(mode)
+        one = r.render(g["novd_pose"], 200, 200, fx=fx, fy=fy, cx=cx, cy=cy, near=0.1, far=10.0, precision="f16x3")
+        assert r.debug_last_plan() == mode and all(torch.equal(one[k], frame["f16x3"][k]) for k in ("rgb", "depth", "acc"))
+    r.debug_set_decomposition(-1)
     r.set_sampling(16, 24)
     # create_rays without the view-direction columns: the first eight columns, bit for bit
     fx, fy, cx, cy = O.intrinsics(800, 800)

@@ -27,5 +27,8 @@ SQ_WAVE_CYCLES SQ_IFETCH SQ_IFETCH_LEVEL SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICAC
 SQ_WAVE_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES SQ_BUSY_CU_CYCLES SQ_INST_LEVEL_LDS SQ_INST_LEVEL_VMEM SQC_TC_INST_REQ SQ_INSTS_VALU_CVT SQ_INSTS_VALU_TRANS_F
 GRBM_GUI_ACTIVE
 LIST
-cd $ROOT && python3 bench.py --steps 6 --warmup 2 > $OUT/r03_bench.json 2> $OUT/r03_bench.err
+# the counters become profiles/r03_pmc_traffic.json ON THIS BOX first, so that the plain run below carries this run's own
+# `traffic` (bench.py takes it only from a profile of the same kernel sources); the same summary is run again at home
+cd $ROOT && rm -f $OUT/r03_bench.json && python3 tools/r03_profile_summary.py > /dev/null
+python3 bench.py --steps 6 --warmup 2 > $OUT/r03_bench.json 2> $OUT/r03_bench.err
 echo "plain bench done"
