@@ -26,8 +26,10 @@
 //     stages between the MFMAs of tile t+1 (EpiPlan), LDS-DMA addressing is scalar and each piece has a
 //     gap of its own (DmaPlan), the A fragments are read three k-steps ahead.
 //   * template switches of render_mfma_kernel: X3 (three split products / single fp16 product), SPLIT (one packet per
-//     workgroup, samples dealt to the waves), FOLD (_feature_linear multiplied into the view layer by the packer, the product
-//     path), LEAN (only rgb / depth / acc of pinhole views: every other pointer compile-time null, no register spills).
+//     workgroup, samples dealt to the waves), FORM (nwe_host.h: kFormFolded = _feature_linear multiplied into the view layer by
+//     the packer and _alpha_linear a dot product, the product path - "FOLD" below; kFormReference = every layer a tile of the
+//     stream; kFormNoViewDirs = trunk + _output_linear), LEAN (only rgb / depth / acc of pinhole views: every other pointer
+//     compile-time null, no register spills).
 // This header holds the templates; nwe_mfma_inst_*.hip instantiate them (in parallel), nwe_kernel_mfma.hip dispatches.
 #pragma once
 #include "nwe_host.h"
@@ -203,6 +205,9 @@ __device__ __forceinline__ void epi_stage(const Pend& t, Epi& E, float inv_scale
             E.v[e] = a;
         }
     } else if (st == 1) {
+        // (v_pk_fma_f32 on element pairs - half the instructions, the same fma per element - measures 1.4 % SLOWER: 368.3 vs
+        // 363.2 ms, alternating on one box; hipcc also needs asm for it and then for the ReLU, whose operand it no longer knows
+        // to be canonical)
 #pragma unroll
         for (int e = e0; e < e0 + P::GS; ++e) {
             const float4 b = t.bias[e >> 2];
