@@ -108,7 +108,8 @@ int nwe_set_network(nwe_ctx *ctx, int which, int depth, int width, int in_xyz, i
  * input_ch_views = 0 and output_ch = 5, handler.py:97-119): the trunk and ONE output layer.  w, b: depth+1 pointers each,
  * _pts_linears[0..depth-1] then _output_linear [output_ch, width]; output_ch >= 4, channels 0..2 are rgb_raw and channel 3
  * sigma_raw (model_utils.py:62,71), further channels are ignored as the reference ignores them.  Such networks render with
- * every precision where the shape is 8x256 (skip after layer 4) or 4x128 (no skip) - the MFMA kernel evaluates the trunk and
+ * every precision where the shape is one the MFMA kernel is instantiated for (widths 128 and 256, depth 6 or 8 with the skip
+ * after layer 4, or depth 4 without) - it evaluates the trunk and
  * then one tile of _output_linear - and with NWE_PREC_F32 otherwise; they take 8-column rays in nwe_render_rays ([o d near far], nerf/rays/rays.py:26-30
  * without the view directions) and both networks of a context must be of the same kind. */
 int nwe_set_network_no_view_dirs(nwe_ctx *ctx, int which, int depth, int width, int in_xyz, int skip_layer, int output_ch,

@@ -363,7 +363,7 @@ int check_ready(nwe_ctx* ctx, const nwe_outputs* out, int precision) {
     if (precision != NWE_PREC_F32) {
         if (!ctx->net[0].mfma_ok || (ctx->ni > 0 && !ctx->net[1].mfma_ok))
             return fail(ctx, NWE_ERR_UNSUPPORTED,
-                        "no MFMA kernel for this network shape (have widths 128 and 256 with depth 6 or 8 and the skip after layer 4, or depth 4 without, 63/27 inputs; without view directions 8x256 and 4x128 only); use NWE_PREC_F32");
+                        "no MFMA kernel for this network shape (have widths 128 and 256 with depth 6 or 8 and the skip after layer 4, or depth 4 without, 63 + 27 or, without view directions, 63 inputs); use NWE_PREC_F32");
         if (ctx->ns > mfma_max_samples())
             return fail(ctx, NWE_ERR_UNSUPPORTED, "the MFMA kernel supports n_samples <= 128; use NWE_PREC_F32");
     }

@@ -10,13 +10,12 @@ template __global__ void render_mfma_kernel<256, 8, 4, true, false, NWE_ONE_KERN
 #else
 // Instantiated shapes: width 128 or 256, even depth 4 / 6 / 8 with the reference's skip connection (after layer 4 where
 // that layer exists and feeds another trunk layer, nerf_model.py:13,58-59; none for depth 4), 63/27-wide encodings.
-// The reference formulation (kFormReference) and the networks without view directions (kFormNoViewDirs) exist for the two
-// BASELINE shapes only.
+// The reference formulation (kFormReference) exists for the two BASELINE shapes only.
 bool mfma_supported(int D, int W, int in_xyz, int in_dir, int skip, int form) {
     if (in_xyz != 63 || in_dir != (form == kFormNoViewDirs ? 0 : 27) || (W != 128 && W != 256)) return false;
     const bool shape = (D == 8 && skip == 4) || (D == 6 && skip == 4) || (D == 4 && skip == -1);
     if (!shape) return false;
-    return form == kFormFolded || (D == 8 && W == 256) || (D == 4 && W == 128);
+    return form != kFormReference || (D == 8 && W == 256) || (D == 4 && W == 128);
 }
 
 int mfma_max_samples() { return kSplitMaxSamples; }
@@ -34,6 +33,10 @@ NWE_EXTERN_SHAPE(128, 6, 4, kFormFolded);
 NWE_EXTERN_SHAPE(128, 4, -1, kFormFolded);
 NWE_EXTERN_SHAPE(128, 4, -1, kFormReference);
 NWE_EXTERN_SHAPE(128, 4, -1, kFormNoViewDirs);
+NWE_EXTERN_SHAPE(256, 6, 4, kFormNoViewDirs);
+NWE_EXTERN_SHAPE(256, 4, -1, kFormNoViewDirs);
+NWE_EXTERN_SHAPE(128, 8, 4, kFormNoViewDirs);
+NWE_EXTERN_SHAPE(128, 6, 4, kFormNoViewDirs);
 #endif
 #undef NWE_EXTERN_SHAPE
 
@@ -57,6 +60,10 @@ bool launch_render_mfma(const RenderArgs& a, const NetMfma& nc, const NetMfma& n
     if (nc.form == kFormNoViewDirs) {
         if (D == 8 && W == 256 && skip == 4) return launch_t<256, 8, 4, kFormNoViewDirs>(a, nc, nf, three_pass, decomposition, stream, info);
         if (D == 4 && W == 128 && skip == -1) return launch_t<128, 4, -1, kFormNoViewDirs>(a, nc, nf, three_pass, decomposition, stream, info);
+        if (D == 6 && W == 256 && skip == 4) return launch_t<256, 6, 4, kFormNoViewDirs>(a, nc, nf, three_pass, decomposition, stream, info);
+        if (D == 4 && W == 256 && skip == -1) return launch_t<256, 4, -1, kFormNoViewDirs>(a, nc, nf, three_pass, decomposition, stream, info);
+        if (D == 8 && W == 128 && skip == 4) return launch_t<128, 8, 4, kFormNoViewDirs>(a, nc, nf, three_pass, decomposition, stream, info);
+        if (D == 6 && W == 128 && skip == 4) return launch_t<128, 6, 4, kFormNoViewDirs>(a, nc, nf, three_pass, decomposition, stream, info);
         return false;
     }
     if (D == 8 && W == 256 && skip == 4) return launch_t<256, 8, 4, kFormReference>(a, nc, nf, three_pass, decomposition, stream, info);

@@ -4,4 +4,5 @@
 namespace nwe {
 template bool launch_t<256, 8, 4, kFormNoViewDirs>(const RenderArgs&, const NetMfma&, const NetMfma&, bool, int, hipStream_t, LaunchInfo*);
 template bool launch_t<128, 4, -1, kFormNoViewDirs>(const RenderArgs&, const NetMfma&, const NetMfma&, bool, int, hipStream_t, LaunchInfo*);
+template bool launch_t<128, 6, 4, kFormNoViewDirs>(const RenderArgs&, const NetMfma&, const NetMfma&, bool, int, hipStream_t, LaunchInfo*);
 }  // namespace nwe

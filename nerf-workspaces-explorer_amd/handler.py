@@ -86,7 +86,7 @@ class NeRFReplicaInferenceHandler:
         self._depth_close_bound, self._depth_far_bound = cfg.get_param(("rendering", "depth_range"), list)
         # rendering.use_view_dirs = False (nerf_model.py:41-43,82-83) and experiment.endpoint_feat = True (:72-81, handler.py:248-271)
         # are off in all four reference YAMLs; both render here: networks without view directions through the MFMA kernel's
-        # own instantiations (8x256 and 4x128; other shapes through the fp32 HIP kernel), the endpoint feature map as
+        # own instantiations (other shapes than its six through the fp32 HIP kernel), the endpoint feature map as
         # `feat_map_fine` of _render_rays (fp32 kernel; frames, which return rgb only, keep the MFMA kernel).
         self._fx, self._fy, self._cx, self._cy = pinhole_intrinsics(self._img_h, self._img_w)
         self._renderer: Optional[Renderer] = None

@@ -1196,8 +1196,8 @@ def test_networks_without_view_dirs(golden_dir, tmp_path, monkeypatch, capsys):
     """NeRFModel(use_view_dirs=False) (nerf_model.py:41-43,82-83): trunk + _output_linear [5, W], 8-column rays (rays.py:22-30),
     against tests/golden/variants.npz (the reference's own classes): the network alone at the embed.npz points, then 16 + 24
     samples end to end with a thin-fog coarse network (every ray at full tolerance) - through the fp32 HIP kernel and through
-    the MFMA kernel's kFormNoViewDirs instantiations (8x256 and 4x128; another shape asked for explicitly is refused, never
-    silently replaced), a 200x200 frame of the MFMA kernel against the fp32 kernel, and the handler with
+    the MFMA kernel's kFormNoViewDirs instantiations (every shape the folded form has; another one asked for explicitly is
+    refused, never silently replaced), a 200x200 frame of the MFMA kernel against the fp32 kernel, and the handler with
     rendering.use_view_dirs: False in its YAML."""
     g = np.load(os.path.join(golden_dir, "variants.npz"))
     ge = np.load(os.path.join(golden_dir, "embed.npz"))
@@ -1264,9 +1264,22 @@ def test_networks_without_view_dirs(golden_dir, tmp_path, monkeypatch, capsys):
     with pytest.raises(RuntimeError, match="both have, or both lack"):
         r.render_rays(rays8.cuda(), precision="f32")
     r.close()
+    # the other instantiated shapes (no reference vectors for them): the MFMA kernel against the fp32 kernel, which the vectors pin
+    for D, Wn, seed in ((6, 256, 2010), (4, 256, 2011), (8, 128, 2012), (6, 128, 2013)):
+        r = nwe_amd.Renderer(0)
+        r.set_network(0, nwe_amd.synthetic.make_state_dict(seed, D, Wn, use_view_dirs=False)); r.set_sampling(2, 0)
+        assert r.mfma_supported(0)
+        ref = r.render_rays(rays_pts, precision="f32", outputs=("raw_coarse",))["raw_coarse"]
+        for mode in (0, 1):
+            r.debug_set_decomposition(mode)
+            got = r.render_rays(rays_pts, precision="f16x3", outputs=("raw_coarse",))["raw_coarse"]
+            err = (got - ref).abs().max().item()
+            print(f"[no view dirs {D}x{Wn} f16x3 decomposition {mode}] raw vs the fp32 kernel: {err:.2e}")
+            assert err <= 5e-6
+        r.close()
     # a shape without an MFMA instantiation: refused when asked for, the fp32 kernel serves it
     r = nwe_amd.Renderer(0)
-    r.set_network(0, nwe_amd.synthetic.make_state_dict(2003, 6, 256, use_view_dirs=False)); r.set_sampling(2, 0)
+    r.set_network(0, nwe_amd.synthetic.make_state_dict(2003, 6, 64, use_view_dirs=False)); r.set_sampling(2, 0)
     assert not r.mfma_supported(0)
     with pytest.raises(NotImplementedError):
         r.render_rays(rays_pts, precision="f16x3", outputs=("raw_coarse",))

@@ -42,7 +42,7 @@ def test_stream_replay_matches_oracle(D, W, seed, folded, n_tiles, n_chunks):
     assert 2e-5 < np.abs(got1 - ref).max() < 5e-2
 
 
-@pytest.mark.parametrize("D,W,seed", [(8, 256, 21), (4, 128, 22)])
+@pytest.mark.parametrize("D,W,seed", [(8, 256, 21), (4, 128, 22), (6, 256, 23), (4, 256, 24), (8, 128, 25), (6, 128, 26)])
 def test_stream_replay_without_view_dirs(D, W, seed):
     """use_view_dirs=False (nerf_model.py:42-43,78-79): layer 0, D-1 trunk layers and ONE chunk of _output_linear - rows 0..3,
     the fifth channel is dropped as the reference drops it (model_utils.py:62,71)."""
@@ -73,9 +73,9 @@ def test_stream_replay_without_view_dirs(D, W, seed):
     assert 2e-5 < np.abs(got1 - ref).max() < 5e-2
 
 
-def test_no_view_dirs_stream_only_for_the_baseline_shapes():
+def test_no_view_dirs_unsupported_shape_has_no_stream():
     r = nwe_amd.Renderer(host_only=True)
-    r.set_network(0, nwe_amd.synthetic.make_state_dict(5, 6, 256, use_view_dirs=False))
+    r.set_network(0, nwe_amd.synthetic.make_state_dict(5, 6, 64, use_view_dirs=False))
     assert r.packed_stream(0).size == 0 and not r.mfma_supported(0)      # the fp32 kernel serves it
 
 
