@@ -5,9 +5,10 @@ import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import nwe_amd
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+view_dirs = not (len(sys.argv) > 2 and sys.argv[2] == "no_view_dirs")   # second argument: the trunk + _output_linear formulation
 r = nwe_amd.Renderer(0)
-r.set_network(0, nwe_amd.synthetic.make_state_dict(1000, 8, 256))
-r.set_network(1, nwe_amd.synthetic.make_state_dict(1001, 8, 256))
+r.set_network(0, nwe_amd.synthetic.make_state_dict(1000, 8, 256, use_view_dirs=view_dirs))
+r.set_network(1, nwe_amd.synthetic.make_state_dict(1001, 8, 256, use_view_dirs=view_dirs))
 r.set_sampling(64, 128)
 fx, fy, cx, cy = nwe_amd.pinhole_intrinsics(800, 800)
 pose = np.array([[0.8660254, 0, 0.5, 0], [-0.5, 0, 0.8660254, -0.76157], [0, -1, 0, 0.5], [0, 0, 0, 1]], np.float32)
